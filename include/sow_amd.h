@@ -1,0 +1,120 @@
+/* sow_amd.h -- C ABI of libsow_amd.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the SoW (Sum-of-Weights) low-rank linear hot path of
+ * antoine311200/sow.  The reference has NO foreign-function interface: its hot
+ * path is Python (tn_gradient/layer/sow.py, tn_gradient/utils.py,
+ * tn_gradient/prepare.py, tn_gradient/tt.py) calling ATen.  Each entry point
+ * below replaces the ATen call sequence of the cited reference lines; the
+ * host-side mirror (the sow_amd Python package) binds them with ctypes and keeps the
+ * reference's class/function surface.
+ *
+ * Conventions:
+ *   - every function returns int: 0 ok, <0 argument error (SOW_ERR_*), >0 hipError_t;
+ *   - nothing here allocates or frees device memory or synchronises the device;
+ *     the caller passes a workspace sized by the matching *_workspace_bytes query;
+ *   - all tensors are dense row-major device buffers, 16-byte aligned for the
+ *     fast paths (unaligned / odd shapes take slower element-wise paths);
+ *   - dtype: SOW_DTYPE_F32 (exact f32 MFMA) or SOW_DTYPE_BF16 (bf16 MFMA, f32 accumulate);
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are
+ *     enqueued on it, so the calls are capturable into a hipGraph;
+ *   - n_iter > 1 is presented as concatenated factors A = [A_1 .. A_n] ([d_in, n*r]),
+ *     B = [B_1; ..; B_n] ([n*r, d_out]); sum_i A_i B_i = A B.
+ */
+#ifndef SOW_AMD_H
+#define SOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOW_DTYPE_F32 0
+#define SOW_DTYPE_BF16 1
+
+#define SOW_OK 0
+#define SOW_ERR_NULL (-1)
+#define SOW_ERR_SHAPE (-2)
+#define SOW_ERR_DTYPE (-3)
+#define SOW_ERR_ALIGN (-4)
+#define SOW_ERR_WORKSPACE (-5)
+#define SOW_ERR_UNSUPPORTED (-6)
+
+/* accumulator kinds of SoWLinear.forward (sow.py:109-112) */
+#define SOW_ACC_NONE 0    /* acc_downweight empty                                   */
+#define SOW_ACC_LOWRANK 1 /* out = (x @ acc_down[d_in,vr]) @ acc_up[vr,d_out]       */
+#define SOW_ACC_DENSE 2   /* out = x @ acc_down[d_in,d_out]                         */
+
+#define SOW_H_COLS 64 /* column count of the saved h / dh buffers when r_live <= 64 */
+
+int sow_version(void);
+const char* sow_error_string(int code);
+
+/* Bytes of workspace needed by sow_forward / sow_backward for this shape. */
+size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);
+/* Elements (of dtype) the caller must allocate for h_save: T*64 when r_live <= 64, else T*r_live. */
+size_t sow_h_save_elems(int64_t T, int r_live);
+
+/* SoWLinear.forward -- replaces sow.py:107-126:
+ *   y = acc_term + scale * (x @ A) @ B + bias,   h_save = x @ A  (kept for backward).
+ * x [T,d_in], A [d_in,r_live], B [r_live,d_out], y [T,d_out]; acc_down/acc_up per acc_kind
+ * (r_acc = vr for SOW_ACC_LOWRANK, ignored otherwise); bias [d_out] or NULL.
+ * The accumulator term is NOT scaled (sow.py:110-112). */
+int sow_forward(const void* x, const void* A, const void* B, const void* acc_down, const void* acc_up, const void* bias,
+                void* y, void* h_save, int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale,
+                int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the above (what autograd derives from sow.py:107-126):
+ *   dh = scale * dY @ B^T ; dB = scale * h^T @ dY ; dA = x^T @ dh ;
+ *   dX = dh @ A^T + acc-term ; dbias = sum_t dY.
+ * Gradients are written as  g = grad_beta * g + new  (grad_beta = 0 overwrites, 1 accumulates).
+ * dbias may be NULL (no bias).  dx must be non-NULL. */
+int sow_backward(const void* dy, const void* x, const void* h_save, const void* A, const void* B, const void* acc_down,
+                 const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out,
+                 int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
+ * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call
+ * sites: accumulate() sow.py:131-140 (W_acc += scale * A @ B, Q @ R), prepare.py:135, tt.py:213-237. */
+int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
+             const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream);
+
+/* Truncated Householder QR -- replaces qr_weight (utils.py:8-30) and the truncated complete-mode QR
+ * of TensorTrain.decompose (tt.py:128-136):  Q_out[m,k] = Q[:, :k], R_out[k,n] = R[:k, :]
+ * with LAPACK's sign convention.  W [m,n] (ldw) of in_dtype; outputs of out_dtype; internals fp32.
+ * R_out may be NULL (sow.py:168-172 only needs Q).  k <= m. */
+size_t sow_qr_workspace_bytes(int m, int n, int k, int in_dtype, int need_r);
+int sow_qr_thin(const void* W, int64_t ldw, int m, int n, int in_dtype, int k, void* Q_out, int64_t ldq, void* R_out,
+                int64_t ldr, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Multi-tensor zero fill -- replaces the per-parameter torch.zeros_like of reset_optimizer
+ * (scripts/utils/training_utils.py:257-277) and B <- 0 of sow.py:159.  ptrs/bytes are HOST arrays. */
+int sow_zero_state(void* const* ptrs, const int64_t* bytes, int n, void* stream);
+
+/* AdamW step over one flat parameter buffer (the factor param group of simple_train.py:502-506).
+ * state_dtype = dtype of exp_avg / exp_avg_sq.  step is the 1-based step count. */
+int sow_adamw_flat(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, int dtype, int state_dtype,
+                   void* stream);
+
+/* TTAdam dense section (ttadam.py:84-111), fp32 buffers. */
+int sow_ttadam_dense(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                     float beta2, float eps, float step_size, float lr_times_wd, int clamp_v, void* stream);
+
+/* TT Hadamard product of two cores (tt.py:469-475): out[(a,c),ij,(b,d)] = A[a,ij,b] * B[c,ij,d], fp32. */
+int sow_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
+                     void* stream);
+
+/* y = a*x + b*y over n elements. */
+int sow_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream);
+
+/* Strided 2-D cast copy between f32 / bf16. */
+int sow_cast_copy(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
+                  int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOW_AMD_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libsow_amd.so (the C ABI declared in include/sow_amd.h).
+
+The library is the product: there is NO CPU or PyTorch fallback behind these
+calls.  If the shared object is missing, or a call returns a non-zero code, a
+RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsow_amd.so")
+
+F32, BF16 = 0, 1
+ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2
+H_COLS = 64
+
+# name -> (restype, argtypes); mirrors include/sow_amd.h one to one
+SIGNATURES = {
+    "sow_version": (c_int, []),
+    "sow_error_string": (c_char_p, [c_int]),
+    "sow_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sow_h_save_elems": (c_size_t, [c_int64, c_int]),
+    "sow_forward": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
+                                               c_size_t, c_void_p]),
+    "sow_backward": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                                 c_void_p, c_size_t, c_void_p]),
+    "sow_gemm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                         c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "sow_qr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "sow_qr_thin": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                            c_void_p, c_size_t, c_void_p]),
+    "sow_zero_state": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p]),
+    "sow_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                               c_float, c_int, c_float, c_int, c_int, c_void_p]),
+    "sow_ttadam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                 c_float, c_int, c_void_p]),
+    "sow_tt_kron_core": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sow_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
+    "sow_cast_copy": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class SowLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsow_amd.so (once).  Raises SowLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SowLibraryError(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). "
+            "sow_amd has no CPU/PyTorch fallback for the SoW hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().sow_error_string(code).decode()
+        raise SowLibraryError(f"libsow_amd {what} failed with code {code}: {msg}")

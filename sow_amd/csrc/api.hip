@@ -1,0 +1,360 @@
+// extern "C" entry points of libsow_amd.so (declared in include/sow_amd.h).
+// Host-side dispatch only: picks the fused low-rank chain / skinny-TN kernels for r <= 64 and composes
+// the dense GEMM kernel for everything else.  No allocation, no synchronisation, no global state.
+#include "kernels.hpp"
+
+namespace sow {
+
+// column sums of a [T, D] matrix (fallback path only: r_live > 64 with bias)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int64_t rows, int D, T* out, float beta) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < D)
+    for (int64_t i = w; i < rows; i += 4) s += to_f32(M[i * ld + c]);
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < D) {
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (beta != 0.f) v += beta * to_f32(out[c]);
+    out[c] = from_f32<T>(v);
+  }
+}
+}  // namespace sow
+
+using namespace sow;
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline size_t esize(int dtype) { return dtype == SOW_F32 ? 4 : 2; }
+static inline bool ok_dtype(int d) { return d == SOW_F32 || d == SOW_BF16; }
+static inline bool al4p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" {
+
+int sow_version(void) { return 100; }
+
+const char* sow_error_string(int code) {
+  switch (code) {
+    case SOW_OK: return "ok";
+    case SOW_ERR_NULL: return "null pointer argument";
+    case SOW_ERR_SHAPE: return "invalid shape argument";
+    case SOW_ERR_DTYPE: return "unsupported dtype";
+    case SOW_ERR_ALIGN: return "misaligned pointer";
+    case SOW_ERR_WORKSPACE: return "workspace too small";
+    case SOW_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_live <= 64 ? 64 : r_live); }
+
+// workspace carve (identical in the query and in the calls)
+struct WsPlan {
+  size_t off_dh, off_t, off_p0, off_p1, total;
+  int ns, slab_len;
+};
+static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
+  WsPlan w{};
+  const size_t es = esize(dtype);
+  size_t off = 0;
+  w.off_dh = off;
+  off += al256((size_t)T * (size_t)(r_live <= 64 ? 64 : r_live) * es);
+  w.off_t = off;
+  if (acc_kind == SOW_ACC_LOWRANK && r_acc > 64) off += al256((size_t)T * r_acc * es);
+  if (r_live <= 64) {
+    const int cg = (d_in + 63) / 64 + (d_out + 63) / 64;
+    w.ns = tn_pick_slabs(T, cg, dtype, &w.slab_len);
+    w.off_p0 = off;
+    off += al256(tn_partial_bytes(w.ns, d_in));
+    w.off_p1 = off;
+    off += al256(tn_partial_bytes(w.ns, d_out));
+  }
+  w.total = off;
+  return w;
+}
+
+size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
+  if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0 || !ok_dtype(dtype)) return 0;
+  return plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype).total + 256;
+}
+
+static char* ws_base(void* workspace) {
+  uintptr_t a = reinterpret_cast<uintptr_t>(workspace);
+  return reinterpret_cast<char*>((a + 255) & ~(uintptr_t)255);
+}
+
+int sow_forward(const void* x, const void* A, const void* B, const void* acc_down, const void* acc_up, const void* bias,
+                void* y, void* h_save, int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale,
+                int dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
+  if (T == 0) return SOW_OK;
+  if (!x || !A || !B || !y) return SOW_ERR_NULL;
+  if (acc_kind != SOW_ACC_NONE && !acc_down) return SOW_ERR_NULL;
+  if (acc_kind == SOW_ACC_LOWRANK && (!acc_up || r_acc <= 0)) return SOW_ERR_SHAPE;
+  if (acc_kind != SOW_ACC_LOWRANK) r_acc = 0;
+  const WsPlan w = plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype);
+  char* ws = workspace ? ws_base(workspace) : nullptr;
+  float beta = 0.f;
+  int rc;
+  if (acc_kind == SOW_ACC_DENSE) {
+    rc = launch_gemm(x, d_in, false, acc_down, d_out, false, y, d_out, nullptr, T, d_out, d_in, 1.f, 0.f, dtype, stream);
+    if (rc) return rc;
+    beta = 1.f;
+  } else if (acc_kind == SOW_ACC_LOWRANK) {
+    if (r_acc <= 64) {
+      ChainParams p{};
+      p.X = x, p.Y = y, p.Hsave = nullptr, p.bias = nullptr;
+      p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
+      p.F1b = acc_down, p.ldf1b = r_acc, p.F2b = acc_up, p.ldf2b = d_out, p.rb = r_acc;
+      p.scale = 1.f, p.beta = 0.f, p.save_scaled = 0;
+      rc = launch_chain(p, dtype, false, stream);
+      if (rc) return rc;
+      beta = 1.f;
+    } else {
+      if (!ws || workspace_bytes < w.total) return SOW_ERR_WORKSPACE;
+      void* t = ws + w.off_t;
+      rc = launch_gemm(x, d_in, false, acc_down, r_acc, false, t, r_acc, nullptr, T, r_acc, d_in, 1.f, 0.f, dtype, stream);
+      if (rc) return rc;
+      rc = launch_gemm(t, r_acc, false, acc_up, d_out, false, y, d_out, nullptr, T, d_out, r_acc, 1.f, 0.f, dtype, stream);
+      if (rc) return rc;
+      beta = 1.f;
+    }
+  }
+  if (r_live <= 64) {
+    ChainParams p{};
+    p.X = x, p.Y = y, p.Hsave = h_save, p.bias = bias;
+    p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
+    p.F1b = A, p.ldf1b = r_live, p.F2b = B, p.ldf2b = d_out, p.rb = r_live;
+    p.scale = scale, p.beta = beta, p.save_scaled = 0;
+    return launch_chain(p, dtype, false, stream);
+  }
+  // generic rank: h = x A ; y = beta*y + scale * h B + bias
+  if (!h_save) return SOW_ERR_NULL;
+  rc = launch_gemm(x, d_in, false, A, r_live, false, h_save, r_live, nullptr, T, r_live, d_in, 1.f, 0.f, dtype, stream);
+  if (rc) return rc;
+  return launch_gemm(h_save, r_live, false, B, d_out, false, y, d_out, bias, T, d_out, r_live, scale, beta, dtype, stream);
+}
+
+int sow_backward(const void* dy, const void* x, const void* h_save, const void* A, const void* B, const void* acc_down,
+                 const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out,
+                 int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
+                 size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
+  if (!dy || !x || !h_save || !A || !B || !dx || !dA || !dB || !workspace) return SOW_ERR_NULL;
+  if (acc_kind != SOW_ACC_NONE && !acc_down) return SOW_ERR_NULL;
+  if (acc_kind == SOW_ACC_LOWRANK && (!acc_up || r_acc <= 0)) return SOW_ERR_SHAPE;
+  if (acc_kind != SOW_ACC_LOWRANK) r_acc = 0;
+  const WsPlan w = plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype);
+  if (workspace_bytes < w.total + 255) return SOW_ERR_WORKSPACE;
+  char* ws = ws_base(workspace);
+  void* dh = ws + w.off_dh;
+  float beta = 0.f;
+  int rc;
+  if (T == 0) {
+    // empty batch: gradients are zero (or unchanged when accumulating)
+    if (grad_beta == 0.f) {
+      void* ptrs[3] = {dA, dB, dbias};
+      int64_t bytes[3] = {(int64_t)d_in * r_live * (int64_t)esize(dtype), (int64_t)r_live * d_out * (int64_t)esize(dtype),
+                          dbias ? (int64_t)d_out * (int64_t)esize(dtype) : 0};
+      return launch_multi_zero(ptrs, bytes, 3, stream);
+    }
+    return SOW_OK;
+  }
+  if (acc_kind == SOW_ACC_DENSE) {
+    // dX = dY . W_acc^T   (W_acc stored [d_in, d_out] = [N, K])
+    rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
+    if (rc) return rc;
+    beta = 1.f;
+  } else if (acc_kind == SOW_ACC_LOWRANK) {
+    if (r_acc <= 64) {
+      // dX = (dY . R_up^T) . Q^T : the same chain kernel with the frozen factors, scale 1
+      ChainParams p{};
+      p.X = dy, p.Y = dx, p.Hsave = nullptr, p.bias = nullptr;
+      p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
+      p.F1b = acc_up, p.ldf1b = d_out, p.F2b = acc_down, p.ldf2b = r_acc, p.rb = r_acc;
+      p.scale = 1.f, p.beta = 0.f, p.save_scaled = 0;
+      rc = launch_chain(p, dtype, true, stream);
+      if (rc) return rc;
+      beta = 1.f;
+    } else {
+      void* t = ws + w.off_t;
+      rc = launch_gemm(dy, d_out, false, acc_up, d_out, true, t, r_acc, nullptr, T, r_acc, d_out, 1.f, 0.f, dtype, stream);
+      if (rc) return rc;
+      rc = launch_gemm(t, r_acc, false, acc_down, r_acc, true, dx, d_in, nullptr, T, d_in, r_acc, 1.f, 0.f, dtype, stream);
+      if (rc) return rc;
+      beta = 1.f;
+    }
+  }
+  if (r_live <= 64) {
+    ChainParams p{};
+    p.X = dy, p.Y = dx, p.Hsave = dh, p.bias = nullptr;
+    p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
+    p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
+    p.scale = scale, p.beta = beta, p.save_scaled = 1;
+    rc = launch_chain(p, dtype, true, stream);
+    if (rc) return rc;
+    // weight gradients: dA = x^T dh ; dB^T = dY^T h ; dbias = colsum(dY) via the all-ones column 63
+    const bool ones_ok = dbias && r_live <= 63;
+    TnParams tp{};
+    tp.njobs = 2, tp.T = T, tp.ns = w.ns, tp.slab_len = w.slab_len;
+    auto vec_ok = [&](const void* ptr, int D) {
+      if (dtype == SOW_F32) return (D % 4 == 0 && al16p(ptr)) ? 1 : 0;
+      return (D % 2 == 0 && al4p(ptr)) ? 1 : 0;
+    };
+    tp.job[0] = TnJob{x, dh, (float*)(ws + w.off_p0), (int64_t)d_in, d_in, -1, (d_in + 63) / 64, vec_ok(x, d_in)};
+    tp.job[1] = TnJob{dy, h_save, (float*)(ws + w.off_p1), (int64_t)d_out, d_out, ones_ok ? 63 : -1, (d_out + 63) / 64,
+                      vec_ok(dy, d_out)};
+    rc = launch_tn(tp, dtype, stream);
+    if (rc) return rc;
+    ReduceParams rp{};
+    rp.njobs = 2, rp.ns = w.ns;
+    rp.job[0] = ReduceJob{(const float*)(ws + w.off_p0), dA, nullptr, (int64_t)r_live, d_in, (d_in + 63) / 64 * 64, r_live, 0, -1,
+                          1.f, grad_beta};
+    rp.job[1] = ReduceJob{(const float*)(ws + w.off_p1), dB, ones_ok ? dbias : nullptr, (int64_t)d_out, d_out,
+                          (d_out + 63) / 64 * 64, r_live, 1, ones_ok ? 63 : -1, scale, grad_beta};
+    rc = launch_tn_reduce(rp, dtype, stream);
+    if (rc) return rc;
+    if (dbias && !ones_ok) {
+      if (dtype == SOW_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3((d_out + 63) / 64), dim3(256), 0, stream, (const float*)dy, (int64_t)d_out, T, d_out, (float*)dbias, grad_beta);
+      else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((d_out + 63) / 64), dim3(256), 0, stream, (const bf16_t*)dy, (int64_t)d_out, T, d_out, (bf16_t*)dbias, grad_beta);
+      SOW_CHECK_LAUNCH();
+    }
+    return SOW_OK;
+  }
+  // generic rank (GEMM composition)
+  rc = launch_gemm(dy, d_out, false, B, d_out, true, dh, r_live, nullptr, T, r_live, d_out, scale, 0.f, dtype, stream);
+  if (rc) return rc;
+  rc = launch_gemm(dh, r_live, false, A, r_live, true, dx, d_in, nullptr, T, d_in, r_live, 1.f, beta, dtype, stream);
+  if (rc) return rc;
+  rc = launch_gemm(x, d_in, true, dh, r_live, false, dA, r_live, nullptr, d_in, r_live, (int)T, 1.f, grad_beta, dtype, stream);
+  if (rc) return rc;
+  rc = launch_gemm(h_save, r_live, true, dy, d_out, false, dB, d_out, nullptr, r_live, d_out, (int)T, scale, grad_beta, dtype, stream);
+  if (rc) return rc;
+  if (dbias) {
+    if (dtype == SOW_F32)
+      hipLaunchKernelGGL(colsum_kernel<float>, dim3((d_out + 63) / 64), dim3(256), 0, stream, (const float*)dy, (int64_t)d_out, T, d_out, (float*)dbias, grad_beta);
+    else
+      hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((d_out + 63) / 64), dim3(256), 0, stream, (const bf16_t*)dy, (int64_t)d_out, T, d_out, (bf16_t*)dbias, grad_beta);
+    SOW_CHECK_LAUNCH();
+  }
+  return SOW_OK;
+}
+
+int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
+             const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream) {
+  return launch_gemm(A, lda, trans_a != 0, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
+}
+
+struct QrPlan {
+  int kc;
+  size_t off_pt, off_qt, off_w, off_r, total;
+};
+static QrPlan plan_qr(int m, int n, int k, int in_dtype, int need_r, int out_dtype_is_f32) {
+  QrPlan q{};
+  q.kc = k < m ? k : m;
+  if (n < q.kc) q.kc = n;
+  size_t off = 0;
+  q.off_pt = off;
+  off += al256((size_t)q.kc * m * 4);
+  q.off_qt = off;
+  off += al256((size_t)k * m * 4);
+  q.off_w = off;
+  if (need_r && n > q.kc && in_dtype != SOW_F32) off += al256((size_t)m * (n - q.kc) * 4);
+  q.off_r = off;
+  if (need_r && n > q.kc && !out_dtype_is_f32) off += al256((size_t)k * (n - q.kc) * 4);
+  q.total = off;
+  return q;
+}
+
+size_t sow_qr_workspace_bytes(int m, int n, int k, int in_dtype, int need_r) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  return plan_qr(m, n, k, in_dtype, need_r, 0).total + 256;
+}
+
+int sow_qr_thin(const void* W, int64_t ldw, int m, int n, int in_dtype, int k, void* Q_out, int64_t ldq, void* R_out,
+                int64_t ldr, int out_dtype, void* workspace, size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ok_dtype(in_dtype) || !ok_dtype(out_dtype)) return SOW_ERR_DTYPE;
+  if (m <= 0 || n <= 0 || k <= 0 || k > m) return SOW_ERR_SHAPE;
+  if (!W || !Q_out || !workspace) return SOW_ERR_NULL;
+  const QrPlan q = plan_qr(m, n, k, in_dtype, R_out != nullptr, out_dtype == SOW_F32);
+  if (workspace_bytes < q.total + 255) return SOW_ERR_WORKSPACE;
+  char* ws = ws_base(workspace);
+  float* Pt = (float*)(ws + q.off_pt);
+  float* Qt = (float*)(ws + q.off_qt);
+  int rc = launch_qr_panel(W, ldw, in_dtype, m, q.kc, k, Pt, Qt, stream);
+  if (rc) return rc;
+  rc = launch_qr_copy_out(Qt, Pt, Q_out, ldq, R_out, ldr, out_dtype, m, q.kc, k, k, stream);
+  if (rc) return rc;
+  if (R_out && n > q.kc) {
+    // R[:k, kc:] = Q[:, :k]^T W[:, kc:]   (fp32 GEMM: A = Qt stored [k, m], B = W columns kc.., k-major)
+    const int nt = n - q.kc;
+    const void* Bp;
+    int64_t ldb;
+    if (in_dtype == SOW_F32) {
+      Bp = (const float*)W + q.kc, ldb = ldw;
+    } else {
+      float* wf = (float*)(ws + q.off_w);
+      rc = launch_cast_copy((const bf16_t*)W + q.kc, ldw, SOW_BF16, wf, nt, SOW_F32, m, nt, stream);
+      if (rc) return rc;
+      Bp = wf, ldb = nt;
+    }
+    if (out_dtype == SOW_F32) {
+      rc = launch_gemm(Qt, m, false, Bp, ldb, false, (float*)R_out + q.kc, ldr, nullptr, k, nt, m, 1.f, 0.f, SOW_F32, stream);
+      if (rc) return rc;
+    } else {
+      float* rt = (float*)(ws + q.off_r);
+      rc = launch_gemm(Qt, m, false, Bp, ldb, false, rt, nt, nullptr, k, nt, m, 1.f, 0.f, SOW_F32, stream);
+      if (rc) return rc;
+      rc = launch_cast_copy(rt, nt, SOW_F32, (bf16_t*)R_out + q.kc, ldr, SOW_BF16, k, nt, stream);
+      if (rc) return rc;
+    }
+  }
+  return SOW_OK;
+}
+
+int sow_zero_state(void* const* ptrs, const int64_t* bytes, int n, void* stream) {
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!ptrs || !bytes) return SOW_ERR_NULL;
+  return launch_multi_zero(ptrs, bytes, n, (hipStream_t)stream);
+}
+
+int sow_adamw_flat(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, int dtype, int state_dtype,
+                   void* stream) {
+  if (step < 1) return SOW_ERR_SHAPE;
+  return launch_adamw_flat(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                           dtype, state_dtype, (hipStream_t)stream);
+}
+
+int sow_ttadam_dense(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                     float beta2, float eps, float step_size, float lr_times_wd, int clamp_v, void* stream) {
+  return launch_ttadam_dense(param, grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, lr_times_wd, clamp_v,
+                             (hipStream_t)stream);
+}
+
+int sow_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
+                     void* stream) {
+  return launch_tt_kron_core(A, B, out, ra0, rb0, ij, ra1, rb1, (hipStream_t)stream);
+}
+
+int sow_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream) {
+  return launch_axpby(x, y, n, a, b, dtype, (hipStream_t)stream);
+}
+
+int sow_cast_copy(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
+                  int cols, void* stream) {
+  if (!src || !dst) return SOW_ERR_NULL;
+  return launch_cast_copy(src, lds, src_dtype, dst, ldd, dst_dtype, rows, cols, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Parameter blocks and host launchers shared between the kernel translation units and api.hip.
+#pragma once
+#include "common.hpp"
+
+namespace sow {
+// chain.hip
+struct ChainParams {
+  const void* X;
+  void* Y;
+  const void *F1a, *F1b, *F2a, *F2b;
+  void* Hsave;
+  const void* bias;
+  int64_t M, ldx, ldy, ldf1a, ldf1b, ldf2a, ldf2b;
+  int D1, D2, ra, rb;
+  float scale, beta;
+  int save_scaled;
+  int fast_factors;
+};
+int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
+// skinny_tn.hip
+struct TnJob {
+  const void* M;
+  const void* S;
+  float* partial;
+  int64_t ldm;
+  int D;
+  int ones_col;
+  int ncg;
+  int vec;
+};
+struct TnParams {
+  TnJob job[2];
+  int njobs;
+  int64_t T;
+  int ns;
+  int slab_len;
+};
+struct ReduceJob {
+  const float* partial;
+  void* out;
+  void* colsum;
+  int64_t out_ld;
+  int D, Dpad, r;
+  int transpose;
+  int ones_col;
+  float alpha, beta;
+};
+struct ReduceParams {
+  ReduceJob job[2];
+  int njobs;
+  int ns;
+  int blocks0;
+};
+int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len);
+size_t tn_partial_bytes(int ns, int D);
+int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
+int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);
+// gemm.hip
+int launch_gemm(const void* A, int64_t lda, bool transA, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
+                const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream);
+// qr.hip
+int launch_cast_copy(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
+                     int cols, hipStream_t stream);
+int launch_qr_panel(const void* W, int64_t ldw, int in_dtype, int m, int kc, int r, float* Pt, float* Qt,
+                    hipStream_t stream);
+int launch_qr_copy_out(const float* Qt, const float* Pt, void* Q, int64_t ldq, void* R, int64_t ldr, int out_dtype, int m,
+                       int kc, int r, int k_rows, hipStream_t stream);
+// misc.hip
+int launch_multi_zero(void* const* ptrs, const int64_t* bytes, int n, hipStream_t stream);
+int launch_adamw_flat(void* p, const void* g, void* m, void* v, int64_t n, float lr, float b1, float b2, float eps,
+                      float wd, int step, float grad_scale, int dtype, int state_dtype, hipStream_t stream);
+int launch_ttadam_dense(float* p, const float* g, float* m, float* v, int64_t n, float b1, float b2, float eps,
+                        float step_size, float lr_wd, int clamp_v, hipStream_t stream);
+int launch_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
+                        hipStream_t stream);
+int launch_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, hipStream_t stream);
+}  // namespace sow

@@ -1,0 +1,118 @@
+"""Data-parallel plumbing for the SoW factor gradients.
+
+The reference wraps the whole model in DistributedDataParallel (simple_train.py:566-572), which
+all-reduces every trainable parameter in 25 MB buckets.  The SoW factors are 112 small tensors
+(llama_60m r=50: 3.9 M elements); here they live in ONE flat parameter buffer and ONE flat gradient
+buffer, so that
+  * the data-parallel exchange is a single RCCL all-reduce over xGMI (backend "nccl" on ROCm),
+    issued on a side stream as soon as the last factor gradient is written and overlapped with the
+    rest of backward,
+  * the optimizer step for the factor group is a single fused kernel (optimizer.FactorAdamW),
+  * reset_optimizer is a single memset.
+Ranks hold identical replicas; tokens are the sharded unit (weak scaling).  The periodic
+accumulate() needs no reduction, but the re-initialised A must be identical on all ranks: either
+identical seeds (what the reference relies on, simple_train.py:217) or `broadcast_factors()`.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .layer import SoWLinear
+
+
+def factor_parameters(model: nn.Module) -> List[nn.Parameter]:
+    """All A_i then B_i of every SoWLinear, in module order (the `special_params` list of
+    simple_train.py:389-405)."""
+    out = []
+    for _, m in model.named_modules():
+        if isinstance(m, SoWLinear):
+            out.extend(list(m.downscale_weights))
+            out.extend(list(m.upscale_weights))
+    return out
+
+
+class FactorBucket:
+    """Re-homes the factor parameters (and their .grad) as views into two flat buffers."""
+
+    def __init__(self, params: Iterable[nn.Parameter]):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("FactorBucket needs at least one parameter")
+        p0 = self.params[0]
+        self.numel = sum(p.numel() for p in self.params)
+        # 64-element alignment of every slot keeps the views 16-byte aligned for the vector paths
+        self.offsets, off = [], 0
+        for p in self.params:
+            if p.dtype != p0.dtype or p.device != p0.device:
+                raise ValueError("FactorBucket parameters must share dtype and device")
+            self.offsets.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.padded_numel = off
+        self.flat_param = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        self.flat_grad = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat_param[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+        self._work = None
+        self._comm_stream: Optional[torch.cuda.Stream] = None
+
+    def rebind(self) -> None:
+        """Call after SoWLinear.accumulate(): `from_weights` rebinds .data to fresh tensors
+        (reference sow.py:37-39); copy them back into the flat buffer and re-point the views."""
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat_param[o:o + p.numel()].view_as(p)
+            if p.data.data_ptr() != view.data_ptr():
+                view.copy_(p.data)
+                p.data = view
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad[o:o + p.numel()].data_ptr():
+                g = self.flat_grad[o:o + p.numel()].view_as(p)
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                p.grad = g
+
+    def zero_grad(self) -> None:
+        if self.flat_grad.is_cuda:
+            from . import ops
+            ops.zero_([self.flat_grad])
+        else:
+            self.flat_grad.zero_()
+
+    # ------------------------------------------------------------------ collectives
+    def all_reduce_async(self, group=None, average: bool = True) -> None:
+        """One sum all-reduce of the whole factor-gradient bucket (RCCL over xGMI on GPUs, gloo on CPU
+        in the tests).  On GPU it runs on a side stream ordered after the current stream."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        op = dist.ReduceOp.SUM
+        if self.flat_grad.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.flat_grad.device)
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                self._work = dist.all_reduce(self.flat_grad, op=op, group=group, async_op=True)
+        else:
+            self._work = dist.all_reduce(self.flat_grad, op=op, group=group, async_op=True)
+        self._average = average
+        self._group = group
+
+    def wait(self) -> float:
+        """Block the current stream on the collective; returns the scale the optimizer must apply to
+        the summed gradient (1/world for averaging -- folded into FactorAdamW.step(grad_scale))."""
+        if self._work is None:
+            return 1.0
+        self._work.wait()
+        if self.flat_grad.is_cuda and self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._work = None
+        return 1.0 / dist.get_world_size(self._group) if self._average else 1.0
+
+    def broadcast_factors(self, src: int = 0, group=None) -> None:
+        """Make the (re-initialised) factors identical on all ranks after accumulate()."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat_param, src=src, group=group)

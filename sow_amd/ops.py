@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C ABI (raw device pointers + the current HIP stream).
+
+PyTorch is used for device memory (the caching allocator owns every buffer), the
+stream and the autograd plumbing only; all arithmetic runs in libsow_amd.so.
+Every function requires CUDA(=HIP) tensors and raises otherwise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"sow_amd supports float32 and bfloat16 tensors, got {t.dtype}") from None
+
+
+def _need_gpu(*ts: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("sow_amd: the SoW hot path runs on MI355X only (got a CPU tensor); "
+                               "there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"sow_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def acc_kind(acc_down: Optional[torch.Tensor], acc_up: Optional[torch.Tensor]) -> int:
+    """Accumulator kind as SoWLinear.forward decides it (reference sow.py:109-112)."""
+    if acc_down is None or acc_down.numel() == 0:
+        return _lib.ACC_NONE
+    if acc_up is None or acc_up.numel() == 0:
+        return _lib.ACC_DENSE
+    return _lib.ACC_LOWRANK
+
+
+def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, acc_up, bias, scale: float):
+    """y, h_save = forward of the SoW contraction on a flattened [T, d_in] input."""
+    lib = _lib.load()
+    dev = _need_gpu(x2, A, B, acc_down if acc_down is not None and acc_down.numel() else None,
+                    acc_up if acc_up is not None and acc_up.numel() else None, bias)
+    dt = _dt(x2)
+    for name, t in (("A", A), ("B", B), ("bias", bias)):
+        if t is not None and t.dtype != x2.dtype:
+            raise TypeError(f"sow_amd: dtype mismatch, x is {x2.dtype} but {name} is {t.dtype}")
+    T, d_in = x2.shape
+    r, d_out = B.shape
+    if A.shape != (d_in, r):
+        raise ValueError(f"sow_amd: A has shape {tuple(A.shape)}, expected {(d_in, r)}")
+    kind = acc_kind(acc_down, acc_up)
+    r_acc = 0
+    if kind == _lib.ACC_DENSE and tuple(acc_down.shape) != (d_in, d_out):
+        raise ValueError("sow_amd: dense accumulator must be [in_features, out_features]")
+    if kind == _lib.ACC_LOWRANK:
+        r_acc = acc_down.shape[1]
+        if acc_down.shape[0] != d_in or tuple(acc_up.shape) != (r_acc, d_out):
+            raise ValueError("sow_amd: low-rank accumulator shapes do not match")
+    if kind != _lib.ACC_NONE and acc_down.dtype != x2.dtype:
+        raise TypeError(f"sow_amd: dtype mismatch, x is {x2.dtype} but the accumulator is {acc_down.dtype}")
+    x2 = x2.contiguous()
+    A, B = A.contiguous(), B.contiguous()
+    acc_down = acc_down.contiguous() if kind != _lib.ACC_NONE else None
+    acc_up = acc_up.contiguous() if kind == _lib.ACC_LOWRANK else None
+    bias = bias.contiguous() if bias is not None else None
+    y = torch.empty((T, d_out), dtype=x2.dtype, device=dev)
+    h = torch.empty(lib.sow_h_save_elems(T, r), dtype=x2.dtype, device=dev)
+    nws = lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt)
+    ws = _ws(nws, dev)
+    _lib.check(lib.sow_forward(_ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y), _ptr(h),
+                               T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), ws.numel(), _stream()),
+               "sow_forward")
+    return y, h
+
+
+def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down,
+                 acc_up, scale: float, need_bias: bool,
+                 out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
+                 grad_beta: float = 0.0):
+    """dx, dA, dB, dbias.  `out` = (dA, dB, dbias) buffers to write/accumulate into (grad_beta)."""
+    lib = _lib.load()
+    dev = _need_gpu(dy2, x2, h, A, B)
+    dt = _dt(x2)
+    if dy2.dtype != x2.dtype:
+        raise TypeError(f"sow_amd: grad dtype {dy2.dtype} differs from input dtype {x2.dtype}")
+    T, d_in = x2.shape
+    r, d_out = B.shape
+    kind = acc_kind(acc_down, acc_up)
+    r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
+    dy2 = dy2.contiguous()
+    dx = torch.empty((T, d_in), dtype=x2.dtype, device=dev)
+    if out is None:
+        dA = torch.empty((d_in, r), dtype=x2.dtype, device=dev)
+        dB = torch.empty((r, d_out), dtype=x2.dtype, device=dev)
+        dbias = torch.empty((d_out,), dtype=x2.dtype, device=dev) if need_bias else None
+        grad_beta = 0.0
+    else:
+        dA, dB, dbias = out
+    nws = lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt)
+    ws = _ws(nws, dev)
+    _lib.check(lib.sow_backward(_ptr(dy2), _ptr(x2), _ptr(h), _ptr(A), _ptr(B),
+                                _ptr(acc_down) if kind != _lib.ACC_NONE else None,
+                                _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
+                                _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale),
+                                float(grad_beta), dt, _ptr(ws), ws.numel(), _stream()), "sow_backward")
+    return dx, dA, dB, dbias
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+         out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
+         bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = alpha * op(A) @ op(B) + beta * out (+ bias).  2-D row-major tensors with unit inner stride."""
+    lib = _lib.load()
+    dev = _need_gpu(A, B, out, bias)
+    dt = _dt(A)
+    if B.dtype != A.dtype:
+        raise TypeError("sow_amd.gemm: operand dtypes differ")
+    if A.dim() != 2 or B.dim() != 2:
+        raise ValueError("sow_amd.gemm expects 2-D tensors")
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    if B.stride(1) != 1:
+        B = B.contiguous()
+    M, K = (A.shape[1], A.shape[0]) if trans_a else A.shape
+    Kb, N = (B.shape[1], B.shape[0]) if trans_b else B.shape
+    if K != Kb:
+        raise ValueError(f"sow_amd.gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=dev)
+        beta = 0.0
+    elif tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.dtype != A.dtype:
+        raise ValueError("sow_amd.gemm: bad output tensor")
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if beta == 0.0:
+            out.zero_()
+        return out
+    _lib.check(lib.sow_gemm(_ptr(A), max(A.stride(0), 1), int(trans_a), _ptr(B), max(B.stride(0), 1), int(trans_b), _ptr(out),
+                            max(out.stride(0), 1), _ptr(bias), M, N, K, float(alpha), float(beta), dt, _stream()), "sow_gemm")
+    return out
+
+
+def qr_thin(W: torch.Tensor, k: int, need_r: bool = True, out_dtype: Optional[torch.dtype] = None):
+    """Q[:, :k], R[:k, :] of the Householder QR of W (LAPACK sign convention), fp32 internals."""
+    lib = _lib.load()
+    dev = _need_gpu(W)
+    if W.dim() != 2:
+        raise ValueError("qr_thin expects a matrix")
+    if W.stride(1) != 1:
+        W = W.contiguous()
+    m, n = W.shape
+    out_dtype = out_dtype or W.dtype
+    if k < 1 or k > m:
+        raise ValueError(f"qr_thin: k={k} out of range for {m} rows")
+    Q = torch.empty((m, k), dtype=out_dtype, device=dev)
+    R = torch.empty((k, n), dtype=out_dtype, device=dev) if need_r else None
+    nws = lib.sow_qr_workspace_bytes(m, n, k, _dt(W), int(need_r))
+    ws = _ws(nws, dev)
+    _lib.check(lib.sow_qr_thin(_ptr(W), W.stride(0), m, n, _dt(W), k, _ptr(Q), k, _ptr(R), n, _DT[out_dtype], _ptr(ws),
+                               ws.numel(), _stream()), "sow_qr_thin")
+    return Q, R
+
+
+def zero_(tensors: Sequence[torch.Tensor]) -> None:
+    """Zero a list of dense device tensors with one (or a few) multi-tensor launches."""
+    lib = _lib.load()
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    _need_gpu(*ts)
+    for t in ts:
+        if not t.is_contiguous():
+            raise ValueError("sow_amd.zero_: tensors must be contiguous")
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in ts])
+    _lib.check(lib.sow_zero_state(ptrs, sizes, n, _stream()), "sow_zero_state")
+
+
+def adamw_flat_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+                betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
+                grad_scale: float = 1.0) -> None:
+    lib = _lib.load()
+    _need_gpu(param, grad, exp_avg, exp_avg_sq)
+    _lib.check(lib.sow_adamw_flat(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, betas[0],
+                                  betas[1], eps, weight_decay, int(step), grad_scale, _dt(param), _dt(exp_avg), _stream()),
+               "sow_adamw_flat")
+
+
+def ttadam_dense_(param, grad, exp_avg, exp_avg_sq, *, beta1, beta2, eps, step_size, lr_times_wd, clamp_v: bool) -> None:
+    lib = _lib.load()
+    _need_gpu(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("ttadam_dense_ expects contiguous float32 tensors")
+    _lib.check(lib.sow_ttadam_dense(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), beta1, beta2,
+                                    eps, step_size, lr_times_wd, int(clamp_v), _stream()), "sow_ttadam_dense")
+
+
+def tt_kron_core(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """einsum('aijb,cijd->acijbd') reshaped to [ra*rc, i, j, rb*rd] (reference tt.py:469-475)."""
+    lib = _lib.load()
+    dev = _need_gpu(a, b)
+    a, b = a.contiguous().float(), b.contiguous().float()
+    ra0, i, j, ra1 = a.shape
+    rb0, i2, j2, rb1 = b.shape
+    if (i, j) != (i2, j2):
+        raise ValueError("tt_kron_core: physical dimensions differ")
+    out = torch.empty((ra0 * rb0, i, j, ra1 * rb1), dtype=torch.float32, device=dev)
+    _lib.check(lib.sow_tt_kron_core(_ptr(a), _ptr(b), _ptr(out), ra0, rb0, i * j, ra1, rb1, _stream()), "sow_tt_kron_core")
+    return out
+
+
+def axpby_(x: torch.Tensor, y: torch.Tensor, a: float, b: float) -> torch.Tensor:
+    """y <- a*x + b*y"""
+    lib = _lib.load()
+    _need_gpu(x, y)
+    if x.dtype != y.dtype or x.numel() != y.numel() or not (x.is_contiguous() and y.is_contiguous()):
+        raise ValueError("axpby_: x and y must be contiguous, same dtype and size")
+    _lib.check(lib.sow_axpby(_ptr(x), _ptr(y), x.numel(), float(a), float(b), _dt(x), _stream()), "sow_axpby")
+    return y
+
+
+class _MatMul(torch.autograd.Function):
+    """2-D a @ b on the MFMA GEMM kernel with autograd (used by the TT layer's core contractions)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc.contiguous()
+        da = gemm(dc, b, trans_b=True) if ctx.needs_input_grad[0] else None   # dC @ B^T
+        db = gemm(a, dc, trans_a=True) if ctx.needs_input_grad[1] else None   # A^T @ dC
+        return da, db
+
+
+def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _MatMul.apply(a, b)

@@ -1,0 +1,300 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(ctypes -> libsow_amd.so), against the golden vectors generated from the reference and against the
+CPU oracle on seeded inputs.  Tolerances: fp32 1e-5 relative to the largest reference magnitude
+(BASELINE.json north_star), bf16 2e-2; integer / index work bit-exact."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden, rel_err
+from oracle import sow_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda"
+
+
+def _mk_layer(g, dtype=torch.float32):
+    from sow_amd import SoWLinear
+    n_iter, rank = int(g["n_iter"]), int(g["rank"])
+    d_in, d_out = g["A0"].shape[0], g["B0"].shape[1]
+    layer = SoWLinear(d_in, d_out, bias="bias" in g, rank=rank, n_iter=n_iter, scale=float(g["scale"]),
+                      init_method="normal", device=DEV, dtype=dtype, init_params=False)
+    for i in range(n_iter):
+        layer.downscale_weights[i].data = g[f"A{i}"].to(DEV, dtype)
+        layer.upscale_weights[i].data = g[f"B{i}"].to(DEV, dtype)
+    if "bias" in g:
+        layer.bias.data = g["bias"].to(DEV, dtype)
+    if "acc_down" in g:
+        layer.acc_downweight = nn.Parameter(g["acc_down"].to(DEV, dtype), requires_grad=False)
+    if "acc_up" in g:
+        layer.acc_upweight = nn.Parameter(g["acc_up"].to(DEV, dtype), requires_grad=False)
+    return layer
+
+
+FWD = ["cfg1_noacc", "cfg1_bias_dense", "cfg1_lowrank", "r50_3d", "r50_3d_dense", "niter2", "niter3_odd", "tiny_T1"]
+
+
+def test_library_loaded():
+    from sow_amd import _lib
+    assert _lib.load().sow_version() >= 100
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("name", FWD)
+def test_forward_backward_golden_fp32(name):
+    g = load_golden("fwdbwd_" + name)
+    layer = _mk_layer(g)
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = layer(x)
+    assert y.shape == g["y"].shape
+    assert rel_err(y.detach().cpu(), g["y"]) < TOL
+    y.backward(g["dy"].to(DEV))
+    assert rel_err(x.grad.cpu(), g["dx"]) < TOL
+    for i in range(int(g["n_iter"])):
+        assert rel_err(layer.downscale_weights[i].grad.cpu(), g[f"dA{i}"]) < TOL
+        assert rel_err(layer.upscale_weights[i].grad.cpu(), g[f"dB{i}"]) < TOL
+    if "bias" in g:
+        assert rel_err(layer.bias.grad.cpu(), g["dbias"]) < TOL
+
+
+SHAPES = [
+    # T, d_in, d_out, r, acc, bias
+    (64, 256, 256, 8, None, False),           # BASELINE config 1
+    (1000, 512, 512, 50, None, False),        # llama_60m attention proj
+    (777, 512, 1376, 50, "dense", False),     # llama_60m gate/up after the first accumulate
+    (515, 1376, 512, 50, None, True),
+    (300, 768, 768, 50, "lowrank", True),     # north-star width
+    (130, 96, 200, 64, None, True),           # r = 64: no free column for the bias trick
+    (257, 100, 36, 70, "dense", True),        # r > 64: GEMM composition path
+    (90, 50, 70, 7, "lowrank", False),        # odd everything: scalar paths
+    (200, 128, 64, 16, "lowrank_big", False), # low-rank accumulator wider than 64
+]
+
+
+def _rand_case(T, d_in, d_out, r, acc, bias, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, d_in, generator=gen)
+    dy = torch.randn(T, d_out, generator=gen)
+    A = torch.linalg.qr(torch.randn(d_in, max(r, 1), generator=gen) * 0.02)[0][:, :r].contiguous() if r <= d_in else torch.randn(d_in, r, generator=gen) * 0.05
+    B = torch.randn(r, d_out, generator=gen) * 0.02
+    b = torch.randn(d_out, generator=gen) * 0.1 if bias else None
+    ad = au = None
+    if acc == "dense":
+        ad = torch.randn(d_in, d_out, generator=gen) * 0.02
+    elif acc == "lowrank":
+        ad, au = torch.randn(d_in, 24, generator=gen) * 0.1, torch.randn(24, d_out, generator=gen) * 0.1
+    elif acc == "lowrank_big":
+        ad, au = torch.randn(d_in, 100, generator=gen) * 0.1, torch.randn(100, d_out, generator=gen) * 0.1
+    return x, dy, A, B, b, ad, au
+
+
+@pytest.mark.parametrize("idx", range(len(SHAPES)))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_backward_vs_oracle(idx, dtype):
+    from sow_amd import ops
+    T, d_in, d_out, r, acc, bias = SHAPES[idx]
+    scale = 0.75
+    x, dy, A, B, b, ad, au = _rand_case(T, d_in, d_out, r, acc, bias, 1234 + idx)
+    cast = lambda t: None if t is None else t.to(dtype)
+    xq, dyq, Aq, Bq, bq, adq, auq = map(cast, (x, dy, A, B, b, ad, au))
+    f = lambda t: None if t is None else t.float()
+    y_ref = O.sow_forward(f(xq), [f(Aq)], [f(Bq)], f(adq), f(auq), scale, f(bq))
+    dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(f(dyq), f(xq), [f(Aq)], [f(Bq)], f(adq), f(auq), scale, bias)
+    g = lambda t: None if t is None else t.to(DEV)
+    y, h = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), g(auq), g(bq), scale)
+    dx, dA, dB, db = ops.sow_backward(g(dyq), g(xq), h, g(Aq), g(Bq), g(adq), g(auq), scale, bias)
+    tol = TOL if dtype == torch.float32 else 2e-2
+    assert rel_err(y.float().cpu(), y_ref) < tol
+    assert rel_err(dx.float().cpu(), dx_ref) < tol
+    assert rel_err(dA.float().cpu(), dA_ref[0]) < tol
+    assert rel_err(dB.float().cpu(), dB_ref[0]) < tol
+    if bias:
+        assert rel_err(db.float().cpu(), db_ref) < tol
+
+
+def test_empty_batch():
+    from sow_amd import SoWLinear
+    layer = SoWLinear(32, 16, bias=True, rank=4, init_method="normal", device=DEV)
+    x = torch.zeros(0, 32, device=DEV, requires_grad=True)
+    y = layer(x)
+    assert y.shape == (0, 16)
+    y.sum().backward()
+    assert float(layer.downscale_weights[0].grad.abs().max()) == 0.0
+
+
+def test_grad_accumulation_beta():
+    """grad_beta = 1 accumulates into existing gradient buffers (flat-bucket path)."""
+    from sow_amd import ops
+    x, dy, A, B, b, _, _ = _rand_case(300, 128, 96, 8, None, True, 77)
+    g = lambda t: t.to(DEV)
+    y, h = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 1.0)
+    _, dA1, dB1, db1 = ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 1.0, True)
+    bufs = (dA1.clone(), dB1.clone(), db1.clone())
+    ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 1.0, True, out=bufs, grad_beta=1.0)
+    assert rel_err(bufs[0].cpu(), 2 * dA1.cpu()) < TOL and rel_err(bufs[1].cpu(), 2 * dB1.cpu()) < TOL
+    assert rel_err(bufs[2].cpu(), 2 * db1.cpu()) < TOL
+
+
+def test_full_size_properties_bf16():
+    """North-star size (T=32768, d=768, r=50, bf16): size-independent properties.
+    y is linear in x; <dY, Y> = <dA, A> = <dB, B> (y is homogeneous of degree 1 in A and in B);
+    <dY, Y> = <dX, X> (adjoint identity)."""
+    from sow_amd import ops
+    T, d, r = 32768, 768, 50
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(T, d, generator=gen, device=DEV, dtype=torch.bfloat16)
+    dy = torch.randn(T, d, generator=gen, device=DEV, dtype=torch.bfloat16)
+    A = (torch.randn(d, r, generator=gen, device=DEV) * 0.04).bfloat16()
+    B = (torch.randn(r, d, generator=gen, device=DEV) * 0.04).bfloat16()
+    y, h = ops.sow_forward(x, A, B, None, None, None, 1.0)
+    y2, _ = ops.sow_forward((2 * x.float()).bfloat16(), A, B, None, None, None, 1.0)
+    assert rel_err(y2.float().cpu(), 2 * y.float().cpu()) < 2e-2
+    dx, dA, dB, _ = ops.sow_backward(dy, x, h, A, B, None, None, 1.0, False)
+    ip = lambda a, b: float((a.double() * b.double()).sum())
+    base = ip(dy, y)
+    assert abs(ip(dA, A) - base) < 2e-2 * abs(base)
+    assert abs(ip(dB, B) - base) < 2e-2 * abs(base)
+    assert abs(ip(dx, x) - base) < 2e-2 * abs(base)
+    # spot-check 64 rows against the oracle
+    rows = torch.arange(0, T, T // 64)
+    y_ref = O.sow_forward(x[rows].float().cpu(), [A.float().cpu()], [B.float().cpu()], None, None, 1.0, None)
+    assert rel_err(y[rows].float().cpu(), y_ref) < 2e-2
+
+
+def test_full_size_fp32_rows_vs_oracle():
+    from sow_amd import ops
+    T, d_in, d_out, r = 32768, 512, 1376, 50
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(T, d_in, generator=gen, device=DEV)
+    dy = torch.randn(T, d_out, generator=gen, device=DEV)
+    A = torch.randn(d_in, r, generator=gen, device=DEV) * 0.04
+    B = torch.randn(r, d_out, generator=gen, device=DEV) * 0.04
+    y, h = ops.sow_forward(x, A, B, None, None, None, 0.5)
+    dx, dA, dB, _ = ops.sow_backward(dy, x, h, A, B, None, None, 0.5, False)
+    rows = torch.arange(7, T, T // 50)
+    y_ref = O.sow_forward(x[rows].cpu(), [A.cpu()], [B.cpu()], None, None, 0.5, None)
+    assert rel_err(y[rows].cpu(), y_ref) < TOL
+    dx_ref, dA_ref, dB_ref, _ = O.sow_backward(dy.cpu(), x.cpu(), [A.cpu()], [B.cpu()], None, None, 0.5, False)
+    assert rel_err(dx.cpu(), dx_ref) < TOL
+    assert rel_err(dA.cpu(), dA_ref[0]) < 2e-5   # K = 32768 reduction: summation-order noise
+    assert rel_err(dB.cpu(), dB_ref[0]) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+ACC = {"lowrank_grow": (48, 40, "normal_QR"), "niter2_normal": (36, 44, "normal"),
+       "dense_prepare_style": (64, 96, "normal_QR"), "cfg1": (256, 256, "normal_QR")}
+QR_TOL = 5e-5  # Householder on the GPU vs LAPACK: same reflectors, different summation order
+
+
+@pytest.mark.parametrize("name", list(ACC))
+def test_accumulate_trace_golden(name, monkeypatch):
+    from sow_amd import SoWLinear
+    g = load_golden("accumulate_" + name)
+    d_in, d_out, init = ACC[name]
+    rank, n_iter, n_calls = int(g["rank"]), int(g["n_iter"]), int(g["n_calls"])
+    layer = SoWLinear(d_in, d_out, bias=False, rank=rank, n_iter=n_iter, scale=float(g["scale"]), init_method=init,
+                      device=DEV, init_params=False)
+    layer.virtual_rank = int(g["vr0"])
+    for c in range(n_calls):
+        for i in range(n_iter):
+            layer.downscale_weights[i].data = g[f"c{c}_A{i}_in"].to(DEV)
+            layer.upscale_weights[i].data = g[f"c{c}_B{i}_in"].to(DEV)
+        draws = [g[f"c{c}_draw{i}"].to(DEV) for i in range(n_iter)]
+        it = iter(draws)
+        if init == "normal_QR":
+            monkeypatch.setattr(layer, "_fresh_gaussian", lambda shape, device, dtype: next(it).to(dtype))
+        else:
+            orig = nn.init.normal_
+            monkeypatch.setattr(nn.init, "normal_", lambda t, *a, **k: t.copy_(next(it)))
+        layer.accumulate()
+        if init != "normal_QR":
+            monkeypatch.setattr(nn.init, "normal_", orig)
+        assert layer.virtual_rank == int(g[f"c{c}_vr"])          # integer schedule bit-exact
+        assert tuple(layer.acc_downweight.shape) == tuple(g[f"c{c}_acc_down"].shape)
+        assert tuple(layer.acc_upweight.shape) == tuple(g[f"c{c}_acc_up"].shape)
+        if layer.acc_upweight.numel():
+            # Q, R individually (same sign convention) and their product
+            assert rel_err(layer.acc_downweight.cpu(), g[f"c{c}_acc_down"]) < QR_TOL
+            assert rel_err(layer.acc_upweight.cpu(), g[f"c{c}_acc_up"]) < QR_TOL
+        else:
+            assert rel_err(layer.acc_downweight.cpu(), g[f"c{c}_acc_down"]) < TOL
+        for i in range(n_iter):
+            assert rel_err(layer.downscale_weights[i].data.cpu(), g[f"c{c}_A{i}_out"]) < QR_TOL
+            assert float(layer.upscale_weights[i].data.abs().max()) == 0.0
+
+
+def test_qr_golden():
+    from sow_amd import ops
+    g = load_golden("qr_svd")
+    for k in ("tall", "wide", "square", "gauss002", "rankdef"):
+        q, r = ops.qr_thin(g[f"{k}_in"].to(DEV), int(g[f"{k}_rank"]))
+        assert rel_err(q.cpu(), g[f"{k}_q"]) < QR_TOL, k
+        assert rel_err(r.cpu(), g[f"{k}_r"]) < QR_TOL, k
+        m, n = g[f"{k}_in"].shape
+        qf, rf = ops.qr_thin(g[f"{k}_in"].to(DEV), min(m, n))
+        assert rel_err(qf.cpu(), g[f"{k}_qfull"]) < 2e-4, k   # later columns accumulate more rounding
+        assert rel_err((qf @ rf).cpu(), g[f"{k}_in"]) < TOL, k
+    qb, rb = ops.qr_thin(g["bf16_in"].to(DEV, torch.bfloat16), 6)
+    assert qb.dtype == torch.bfloat16
+    assert rel_err(qb.float().cpu(), g["bf16_q"]) < 1e-2 and rel_err(rb.float().cpu(), g["bf16_r"]) < 1e-2
+
+
+def test_qr_llama_shapes_orthonormal():
+    from sow_amd import ops
+    for m, n, k in ((512, 512, 50), (1376, 512, 50), (512, 1376, 50), (4096, 64, 8)):
+        w = torch.randn(m, n, device=DEV) * 0.02
+        q, _ = ops.qr_thin(w, k, need_r=False)
+        eye = (q.t() @ q).cpu()
+        assert rel_err(eye, torch.eye(k)) < 1e-5
+        q_ref, _ = O.qr_weight(w.cpu(), k)
+        assert rel_err(q.cpu(), q_ref) < QR_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm(dtype, ta, tb):
+    from sow_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for (M, N, K) in ((256, 256, 256), (130, 70, 50), (512, 1376, 50), (33, 257, 129)):
+        a = torch.randn((K, M) if ta else (M, K), generator=gen).to(dtype)
+        b = torch.randn((N, K) if tb else (K, N), generator=gen).to(dtype)
+        c0 = torch.randn(M, N, generator=gen).to(dtype)
+        ref = 0.5 * ((a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())) + 2.0 * c0.float()
+        out = ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, out=c0.to(DEV).clone(), alpha=0.5, beta=2.0)
+        assert rel_err(out.float().cpu(), ref) < (TOL if dtype == torch.float32 else 2e-2), (M, N, K)
+
+
+def test_zero_state_and_reset_optimizer():
+    from sow_amd import reset_optimizer
+    torch.manual_seed(0)
+    ps = [nn.Parameter(torch.randn(s, device=DEV)) for s in ((6, 4), (4, 3), (129,), (3, 5))]
+    opt = torch.optim.AdamW([{"params": ps[:1]}, {"params": ps[1:]}], lr=1e-2)
+    for _ in range(2):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step()
+    keep = opt.state[ps[0]]["exp_avg"].clone()
+    reset_optimizer(opt, group_id=1)
+    assert torch.equal(opt.state[ps[0]]["exp_avg"], keep)
+    for p in ps[1:]:
+        st = opt.state[p]
+        assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+        assert float(st["step"]) == 0.0
+
+
+def test_adamw_flat_matches_torch():
+    from sow_amd import ops
+    torch.manual_seed(1)
+    p = torch.randn(1000, device=DEV)
+    ref = nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=0.1)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = torch.randn(1000, device=DEV)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adamw_flat_(p, g, m, v, lr=1e-2, weight_decay=0.1, step=step)
+        assert rel_err(p.cpu(), ref.data.cpu()) < 1e-5
