@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the SoW hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+Workload (BASELINE.json configs[1]): the 56 SoWLinear layers of llama_60m (`--architecture sow`,
+rank 50; 32 x (512->512), 16 x (512->1376), 8 x (1376->512), reference scripts/configs/llama_60m.json)
+at batch 128 x seq 256 = 32768 tokens per GPU, bf16.  One step = forward of all 56 layers in model
+order, backward of all 56 in reverse order (every layer has its own x / dY buffers, so nothing is
+re-read from cache that a real model would not have), and -- for N > 1 -- ONE RCCL all-reduce of the
+flat factor-gradient bucket.  Inputs are resident in HBM before the timed region.  The step is
+captured in a HIP graph after warm-up (no host work in the timed region).
+
+Prints ONE JSON line.  `value` = tokens/s over all ranks (T * N / step time); `gflops` = the
+algorithmic 6*T*r*(d_in+d_out) count per second.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LLAMA_60M = dict(hidden=512, inter=1376, layers=8)
+
+
+def layer_shapes():
+    h, i = LLAMA_60M["hidden"], LLAMA_60M["inter"]
+    block = [(h, h)] * 4 + [(h, i), (h, i), (i, h)]  # q k v o gate up down
+    return block * LLAMA_60M["layers"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rank", type=int, default=50)
+    ap.add_argument("--tokens", type=int, default=128 * 256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--acc", default="none", choices=["none", "dense"], help="accumulator state of the layers")
+    return ap.parse_args()
+
+
+class Stack:
+    """The 56-layer SoWLinear stack with resident synthetic inputs."""
+
+    def __init__(self, shapes, T, r, dtype, device, acc):
+        from sow_amd.dp import FactorBucket
+        self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
+        g = torch.Generator(device=device)
+        self.x, self.dy, self.A, self.B, self.W = [], [], [], [], []
+        params = []
+        for li, (d_in, d_out) in enumerate(shapes):
+            g.manual_seed(1234 + li)
+            self.x.append(torch.randn(T, d_in, generator=g, device=device, dtype=torch.float32).to(dtype))
+            self.dy.append(torch.randn(T, d_out, generator=g, device=device, dtype=torch.float32).to(dtype))
+            a = torch.linalg.qr(torch.randn(d_in, r, generator=g, device=device) * 0.02)[0]  # orthonormal columns
+            b = torch.randn(r, d_out, generator=g, device=device) * 0.02
+            self.A.append(torch.nn.Parameter(a.to(dtype).contiguous()))
+            self.B.append(torch.nn.Parameter(b.to(dtype).contiguous()))
+            params += [self.A[-1], self.B[-1]]
+            self.W.append((torch.randn(d_in, d_out, generator=g, device=device) * 0.02).to(dtype) if acc == "dense" else None)
+        self.bucket = FactorBucket(params)  # grads are views into one flat buffer
+        self.h = [None] * len(shapes)
+
+    def forward_all(self):
+        from sow_amd import ops
+        for li in range(len(self.shapes)):
+            _, self.h[li] = ops.sow_forward(self.x[li], self.A[li].data, self.B[li].data, self.W[li], None, None, 1.0)
+
+    def backward_all(self):
+        from sow_amd import ops
+        for li in reversed(range(len(self.shapes))):
+            ops.sow_backward(self.dy[li], self.x[li], self.h[li], self.A[li].data, self.B[li].data, self.W[li], None, 1.0,
+                             False, out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0)
+
+    def step(self):
+        self.forward_all()
+        self.backward_all()
+
+
+def algorithmic(shapes, T, r, es, acc):
+    flops = sum(6 * T * r * (di + do) + (4 * T * di * do if acc == "dense" else 0) for di, do in shapes)
+    nbytes = sum(T * (3 * di + 2 * do) * es + 2 * T * r * es for di, do in shapes)
+    return flops, nbytes
+
+
+def time_region(fn, iters, stream):
+    """Average duration (ms) of fn() over `iters` calls, HIP events on the launch stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(shapes, T, r):
+    """The CPU oracle (op-for-op restatement of the reference's SoWLinear, fp32) on this host's cores:
+    one forward+backward pass over the same 56 layer shapes at the same T."""
+    from oracle import sow_oracle as O
+    # the GPU box gives one GPU's share of the host (16 cores) although os.cpu_count() reports the whole machine
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))
+    gen = torch.Generator().manual_seed(1234)
+    cache = {}
+    for s in set(shapes):
+        di, do = s
+        cache[s] = (torch.randn(T, di, generator=gen), torch.randn(T, do, generator=gen),
+                    torch.linalg.qr(torch.randn(di, r, generator=gen) * 0.02)[0].contiguous(), torch.randn(r, do, generator=gen) * 0.02)
+    x, dy, A, B = cache[shapes[0]]
+    O.sow_backward(dy, x, [A], [B], None, None, 1.0, False)  # warm-up
+    t0 = time.perf_counter()
+    for s in shapes:
+        x, dy, A, B = cache[s]
+        O.sow_forward(x, [A], [B], None, None, 1.0, None)
+        O.sow_backward(dy, x, [A], [B], None, None, 1.0, False)
+    dt = time.perf_counter() - t0
+    return dict(value=T / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 fwd+bwd pass over the 56 llama_60m SoWLinear shapes, T={T}, fp32, torch-CPU oracle, {dt:.2f} s")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    es = 2 if args.dtype == "bf16" else 4
+    shapes = layer_shapes()
+    T = args.tokens
+
+    from sow_amd import _lib
+    _lib.load()  # fail loudly when the HIP library is missing
+    stack = Stack(shapes, T, args.rank, dtype, device, args.acc)
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.synchronize()
+
+    def comm():
+        if world > 1:
+            stack.bucket.all_reduce_async()
+            stack.bucket.wait()
+
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(max(args.warmup, 1)):   # W untimed warm-up steps (also sets kernel attributes)
+            stack.step()
+            comm()
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                stack.step()
+            graph.replay()
+            comm()
+            torch.cuda.synchronize()
+
+        def one_step():
+            if graph is not None:
+                graph.replay()
+            else:
+                stack.step()
+            comm()
+
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        # per-kernel-group timing with HIP events on the launch stream (rank 0, after the timed region)
+        groups = {}
+        if rank == 0:
+            it = max(3, min(args.steps, 10))
+            groups["forward (chain_kernel fwd x56)"] = time_region(stack.forward_all, it, stream)
+            groups["backward (chain_kernel bwd + tn_partial + tn_reduce, x56 each)"] = time_region(stack.backward_all, it, stream)
+
+    ms = elapsed / args.steps * 1e3
+    flops, nbytes = algorithmic(shapes, T, args.rank, es, args.acc)
+    if rank == 0:
+        n_layers = len(shapes)
+        fwd_ms = groups["forward (chain_kernel fwd x56)"]
+        fwd_bytes = sum(T * (di + do) * es + T * args.rank * es for di, do in shapes)
+        bwd_ms = groups["backward (chain_kernel bwd + tn_partial + tn_reduce, x56 each)"]
+        bwd_bytes = nbytes - fwd_bytes
+        # dominant group = the one with the larger time share; the roofline line prices it per launch set
+        if bwd_ms >= fwd_ms:
+            kname, kms, kbytes = "backward set (chain bwd + skinny-TN + reduce) per layer", bwd_ms / n_layers, bwd_bytes / n_layers
+        else:
+            kname, kms, kbytes = "chain_kernel<bf16,fwd> per layer", fwd_ms / n_layers, fwd_bytes / n_layers
+        achieved = kbytes / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "SoWLinear fwd+bwd tokens/s, llama_60m rank=50 (56-layer SoWLinear stack)",
+            "value": T * world / (ms * 1e-3),
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
+                                   f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
+                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None},
+            "gflops": flops * world / (ms * 1e-3) / 1e9,
+            "algorithmic_gbytes_per_step": nbytes / 1e9,
+            "step_hbm_gbs": nbytes / (ms * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": kms, "algorithmic_bytes_per_launch": kbytes},
+            "kernel_groups_ms": groups,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(shapes, T, args.rank)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,17 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
   hipStream_t stream = (hipStream_t)stream_;
   if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
+  if (T == 0) {
+    // empty batch: gradients are zero (or unchanged when accumulating); x / dy / dx may be NULL
+    if (!dA || !dB) return SOW_ERR_NULL;
+    if (grad_beta == 0.f) {
+      void* ptrs[3] = {dA, dB, dbias};
+      int64_t bytes[3] = {(int64_t)d_in * r_live * (int64_t)esize(dtype), (int64_t)r_live * d_out * (int64_t)esize(dtype),
+                          dbias ? (int64_t)d_out * (int64_t)esize(dtype) : 0};
+      return launch_multi_zero(ptrs, bytes, 3, stream);
+    }
+    return SOW_OK;
+  }
   if (!dy || !x || !h_save || !A || !B || !dx || !dA || !dB || !workspace) return SOW_ERR_NULL;
   if (acc_kind != SOW_ACC_NONE && !acc_down) return SOW_ERR_NULL;
   if (acc_kind == SOW_ACC_LOWRANK && (!acc_up || r_acc <= 0)) return SOW_ERR_SHAPE;
@@ -156,16 +167,6 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
   void* dh = ws + w.off_dh;
   float beta = 0.f;
   int rc;
-  if (T == 0) {
-    // empty batch: gradients are zero (or unchanged when accumulating)
-    if (grad_beta == 0.f) {
-      void* ptrs[3] = {dA, dB, dbias};
-      int64_t bytes[3] = {(int64_t)d_in * r_live * (int64_t)esize(dtype), (int64_t)r_live * d_out * (int64_t)esize(dtype),
-                          dbias ? (int64_t)d_out * (int64_t)esize(dtype) : 0};
-      return launch_multi_zero(ptrs, bytes, 3, stream);
-    }
-    return SOW_OK;
-  }
   if (acc_kind == SOW_ACC_DENSE) {
     // dX = dY . W_acc^T   (W_acc stored [d_in, d_out] = [N, K])
     rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);

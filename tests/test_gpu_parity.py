@@ -220,7 +220,8 @@ def test_accumulate_trace_golden(name, monkeypatch):
             assert rel_err(layer.acc_downweight.cpu(), g[f"c{c}_acc_down"]) < QR_TOL
             assert rel_err(layer.acc_upweight.cpu(), g[f"c{c}_acc_up"]) < QR_TOL
         else:
-            assert rel_err(layer.acc_downweight.cpu(), g[f"c{c}_acc_down"]) < TOL
+            # a dense accumulator that absorbed earlier truncated-QR stages inherits their tolerance
+            assert rel_err(layer.acc_downweight.cpu(), g[f"c{c}_acc_down"]) < (TOL if c == 0 or name == "dense_prepare_style" else QR_TOL)
         for i in range(n_iter):
             assert rel_err(layer.downscale_weights[i].data.cpu(), g[f"c{c}_A{i}_out"]) < QR_TOL
             assert float(layer.upscale_weights[i].data.abs().max()) == 0.0
@@ -229,7 +230,7 @@ def test_accumulate_trace_golden(name, monkeypatch):
 def test_qr_golden():
     from sow_amd import ops
     g = load_golden("qr_svd")
-    for k in ("tall", "wide", "square", "gauss002", "rankdef"):
+    for k in ("tall", "wide", "square", "gauss002"):
         q, r = ops.qr_thin(g[f"{k}_in"].to(DEV), int(g[f"{k}_rank"]))
         assert rel_err(q.cpu(), g[f"{k}_q"]) < QR_TOL, k
         assert rel_err(r.cpu(), g[f"{k}_r"]) < QR_TOL, k
@@ -237,6 +238,16 @@ def test_qr_golden():
         qf, rf = ops.qr_thin(g[f"{k}_in"].to(DEV), min(m, n))
         assert rel_err(qf.cpu(), g[f"{k}_qfull"]) < 2e-4, k   # later columns accumulate more rounding
         assert rel_err((qf @ rf).cpu(), g[f"{k}_in"]) < TOL, k
+    # adversarial input: the 8 leading columns are parallel, so reflectors 2..8 are built from rounding
+    # noise and differ between ANY two implementations (LAPACK builds included).  Well-defined parts:
+    # the first reflector, orthonormality, exact reproduction of the factored panel, and the (kept, not
+    # "fixed") lossiness of unpivoted truncation.
+    w = g["rankdef_in"].to(DEV)
+    q, r = ops.qr_thin(w, 8)
+    assert rel_err(q[:, 0].cpu(), g["rankdef_q"][:, 0]) < QR_TOL and rel_err(r[0].cpu(), g["rankdef_r"][0]) < QR_TOL
+    assert rel_err((q.t() @ q).cpu(), torch.eye(8)) < 1e-5
+    assert rel_err((q @ r)[:, :8].cpu(), g["rankdef_in"][:, :8]) < 1e-5
+    assert rel_err((q @ r).cpu(), g["rankdef_in"]) > 0.1
     qb, rb = ops.qr_thin(g["bf16_in"].to(DEV, torch.bfloat16), 6)
     assert qb.dtype == torch.bfloat16
     assert rel_err(qb.float().cpu(), g["bf16_q"]) < 1e-2 and rel_err(rb.float().cpu(), g["bf16_r"]) < 1e-2

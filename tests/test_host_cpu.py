@@ -1,0 +1,202 @@
+"""CPU tests of the host logic: C-ABI surface, module surgery, state-dict layout, checkpoint loader,
+flat factor bucket + world_size-2 gloo all-reduce.  No GPU compute is attempted here."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import GOLDEN, ROOT, load_golden
+
+
+def test_cabi_exports_every_declared_symbol():
+    from sow_amd import _lib
+    header = open(os.path.join(ROOT, "include", "sow_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sow_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.sow_version() >= 100
+    assert loaded.sow_error_string(-5) == b"workspace too small"
+    assert loaded.sow_workspace_bytes(32768, 512, 512, 50, 0, 0, 1) > 0
+    assert loaded.sow_h_save_elems(100, 50) == 6400 and loaded.sow_h_save_elems(100, 70) == 7000
+
+
+def test_product_has_no_cpu_fallback_and_no_oracle_import():
+    from sow_amd import SoWLinear, ops
+    layer = SoWLinear(16, 12, rank=4, init_method="normal")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.randn(2, 16))
+    with pytest.raises(RuntimeError):
+        layer.accumulate()
+    with pytest.raises(RuntimeError):
+        ops.qr_thin(torch.randn(8, 4), 2)
+    with pytest.raises(RuntimeError):
+        SoWLinear(16, 12, rank=4, init_method="normal_QR")  # reference hard-codes "cuda" there too
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sow_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_sowlinear_surface_matches_reference():
+    from sow_amd import SoWLinear, SoWParameter
+    layer = SoWLinear(20, 12, bias=True, rank=5, n_iter=2, scale=0.5, init_method="normal")
+    assert list(layer.state_dict().keys()) == ["acc_upweight", "acc_downweight", "bias", "downscale_weights.0",
+                                                "downscale_weights.1", "upscale_weights.0", "upscale_weights.1"]
+    assert layer.virtual_rank == 10 and layer.acc_upweight.numel() == 0 and not layer.acc_downweight.requires_grad
+    assert isinstance(layer.downscale_weights, SoWParameter) and layer.downscale_weights[0].shape == (20, 5)
+    assert layer.upscale_weights[1].shape == (5, 12)
+    p0 = layer.downscale_weights[0]
+    layer.downscale_weights.from_weights([torch.ones(20, 5), torch.ones(20, 5)])
+    assert layer.downscale_weights[0] is p0 and float(p0.data.sum()) == 100.0   # Parameter identity survives
+    assert SoWLinear(300, 200, rank=16, n_iter=1, init_method="normal").virtual_rank == 16
+    assert "rank=5" in layer.extra_repr()
+
+
+def test_prepare_sow_names_bit_exact():
+    transformers = pytest.importorskip("transformers")
+    from sow_amd import SoWConfig, SoWLinear, prepare_sow
+    with open(os.path.join(GOLDEN, "prepare_names.json")) as f:
+        P = json.load(f)
+    cfgs = {
+        "llama_60m": transformers.LlamaConfig(hidden_size=512, intermediate_size=1376, num_hidden_layers=8,
+                                              num_attention_heads=8, vocab_size=32000, tie_word_embeddings=False),
+        "roberta": transformers.RobertaConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                              num_attention_heads=12, vocab_size=50265, max_position_embeddings=514,
+                                              type_vocab_size=1),
+    }
+    for key, cfg in cfgs.items():
+        with torch.device("meta"):
+            model = transformers.AutoModelForCausalLM.from_config(cfg)
+        assert [[n, isinstance(m, nn.Linear)] for n, m in model.named_modules()] == P[key]["named_modules"], key
+        model = prepare_sow(model, SoWConfig(target_modules=P[key]["targets"], rank=8, init_method="normal",
+                                             decompose=None, device="meta"))
+        got = [n for n, m in model.named_modules() if isinstance(m, SoWLinear)]
+        assert got == P[key]["replaced"], key
+        shapes = {n: [m.in_features, m.out_features, m.virtual_rank] for n, m in model.named_modules()
+                  if isinstance(m, SoWLinear)}
+        assert shapes == P[key]["shapes"]
+    # llama_7b: names only (module tree from the golden file, matching logic from the product)
+    from sow_amd.prepare import _is_target
+    t7 = P["llama_7b"]["targets"]
+    ms = max(len(t.split(".")) for t in t7)
+    lin, notlin = nn.Linear(1, 1), nn.Identity()
+    got = [n for n, is_lin in P["llama_7b"]["named_modules"] if _is_target(n, lin if is_lin else notlin, t7, ms)]
+    assert got == P["llama_7b"]["replaced"] and len(got) == 160
+
+
+def test_prepare_keep_on_cpu_and_bias_carry():
+    from sow_amd import SoWConfig, SoWLinear, prepare_sow
+    g = load_golden("prepare_keep")
+    m = nn.Sequential()
+    m.add_module("fc1", nn.Linear(20, 12, bias=True))
+    m.add_module("fc2", nn.Linear(12, 6, bias=False))
+    m.fc1.weight.data, m.fc1.bias.data, m.fc2.weight.data = g["w1"], g["b1"], g["w2"]
+    bias_obj = m.fc1.bias
+    m = prepare_sow(m, SoWConfig(target_modules=["fc1", "fc2"], rank=4, scale=0.5, init_method="normal", decompose="keep",
+                                 device="cpu"))
+    assert isinstance(m.fc1, SoWLinear) and m.fc1.bias is bias_obj
+    assert torch.equal(m.fc1.acc_downweight, g["fc1_acc_down"]) and torch.equal(m.fc2.acc_downweight, g["fc2_acc_down"])
+    assert m.fc1.virtual_rank == 12 and m.fc2.virtual_rank == 6 and m.fc1.scale == 0.5
+    assert m.fc2.bias is None and m.fc1.acc_upweight.numel() == 0
+
+
+def test_load_sow_roundtrip(tmp_path):
+    from safetensors.torch import save_file
+
+    from sow_amd import SoWLinear, load_sow
+
+    def make():
+        net = nn.Sequential()
+        net.add_module("a", SoWLinear(10, 8, bias=True, rank=3, init_method="normal"))
+        net.add_module("b", SoWLinear(8, 6, bias=False, rank=3, init_method="normal"))
+        return net
+
+    torch.manual_seed(0)
+    src = make()
+    src.a.acc_downweight = nn.Parameter(torch.randn(10, 8), requires_grad=False)            # dense accumulator
+    src.b.acc_downweight = nn.Parameter(torch.randn(8, 3), requires_grad=False)             # low-rank accumulator
+    src.b.acc_upweight = nn.Parameter(torch.randn(3, 6), requires_grad=False)
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in src.state_dict().items() if v.numel() > 0}, path)
+    dst = make()
+    assert dst.a.acc_downweight.numel() == 0
+    load_sow(dst, path)
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    assert not dst.a.acc_downweight.requires_grad and tuple(dst.b.acc_upweight.shape) == (3, 6)
+
+
+def test_reset_optimizer_cpu_state_matches_golden():
+    from sow_amd import reset_optimizer
+    g = load_golden("reset_optimizer")
+    ps = [nn.Parameter(torch.zeros(s)) for s in ((6, 4), (4, 3), (3, 5))]
+    opt = torch.optim.AdamW([{"params": ps[:1], "lr": 1e-3}, {"params": ps[1:], "lr": 1e-2}])
+    for i, p in enumerate(ps):
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            v = g[f"before_p{i}_{k}"]
+            opt.state[p][k] = v.clone() if torch.is_tensor(v) else torch.tensor(float(v))
+    reset_optimizer(opt, group_id=1)
+    for i, p in enumerate(ps):
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            want = g[f"after_p{i}_{k}"]
+            want = want if torch.is_tensor(want) else torch.tensor(float(want))
+            assert torch.equal(opt.state[p][k].float(), want.float()), (i, k)
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[3])
+rank, world = int(sys.argv[1]), 2
+dist.init_process_group("gloo", init_method="file://" + sys.argv[2], rank=rank, world_size=world)
+import torch.nn as nn
+from sow_amd import SoWLinear, FactorBucket, factor_parameters
+torch.manual_seed(0)
+net = nn.Sequential(SoWLinear(12, 10, bias=False, rank=4, init_method="normal"), SoWLinear(10, 6, bias=True, rank=4, init_method="normal"))
+params = factor_parameters(net)
+assert len(params) == 4
+before = [p.data.clone() for p in params]
+bucket = FactorBucket(params)
+assert all(torch.equal(p.data, b) for p, b in zip(params, before))           # re-homing keeps the values
+assert all(p.data.data_ptr() >= bucket.flat_param.data_ptr() for p in params)
+for i, p in enumerate(params):
+    p.grad.fill_(float((rank + 1) * (i + 1)))                                   # writes land in the flat buffer
+bucket.all_reduce_async()
+scale = bucket.wait()
+assert abs(scale - 0.5) < 1e-12
+for i, p in enumerate(params):
+    assert torch.all(p.grad == 3.0 * (i + 1)), (i, p.grad.flatten()[:3])       # 1x + 2x summed in ONE collective
+# accumulate()-style rebinding: new tensors appear, rebind() copies them back into the bucket
+params[0].data = torch.full_like(params[0].data, 7.0 + rank)
+bucket.rebind()
+assert params[0].data.data_ptr() == bucket.flat_param.data_ptr()
+bucket.broadcast_factors(src=0)
+assert torch.all(params[0].data == 7.0)                                         # rank 1 now holds rank 0's factors
+bucket.zero_grad()
+assert float(bucket.flat_grad.abs().sum()) == 0.0
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_factor_bucket_allreduce_gloo_world2(tmp_path):
+    store = str(tmp_path / "store")
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_DP_WORKER)
+    procs = [subprocess.Popen([sys.executable, script, str(r), store, ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
