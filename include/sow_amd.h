@@ -57,7 +57,8 @@ size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc
 size_t sow_h_save_elems(int64_t T, int r_live);
 
 /* SoWLinear.forward -- replaces sow.py:107-126:
- *   y = acc_term + scale * (x @ A) @ B + bias,   h_save = x @ A  (kept for backward).
+ *   y = acc_term + scale * (x @ A) @ B + bias,   h_save = scale * (x @ A) for r_live <= 64 (padded to 64
+ *   columns, column 63 = 1.0 when free) or x @ A for r_live > 64; opaque to the caller, kept for backward.
  * x [T,d_in], A [d_in,r_live], B [r_live,d_out], y [T,d_out]; acc_down/acc_up per acc_kind
  * (r_acc = vr for SOW_ACC_LOWRANK, ignored otherwise); bias [d_out] or NULL.
  * The accumulator term is NOT scaled (sow.py:110-112). */

@@ -208,9 +208,10 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
       if (dtype == SOW_F32) return (D % 4 == 0 && al16p(ptr)) ? 1 : 0;
       return (D % 2 == 0 && al4p(ptr)) ? 1 : 0;
     };
-    tp.job[0] = TnJob{x, dh, (float*)(ws + w.off_p0), (int64_t)d_in, d_in, -1, (d_in + 63) / 64, vec_ok(x, d_in)};
+    // the chain kernels write 1.0 into column 63 of h_save / dh whenever r_live <= 63
+    tp.job[0] = TnJob{x, dh, (float*)(ws + w.off_p0), (int64_t)d_in, d_in, -1, (d_in + 63) / 64, vec_ok(x, d_in), 1};
     tp.job[1] = TnJob{dy, h_save, (float*)(ws + w.off_p1), (int64_t)d_out, d_out, ones_ok ? 63 : -1, (d_out + 63) / 64,
-                      vec_ok(dy, d_out)};
+                      vec_ok(dy, d_out), 1};
     rc = launch_tn(tp, dtype, stream);
     if (rc) return rc;
     ReduceParams rp{};
@@ -218,7 +219,7 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
     rp.job[0] = ReduceJob{(const float*)(ws + w.off_p0), dA, nullptr, (int64_t)r_live, d_in, (d_in + 63) / 64 * 64, r_live, 0, -1,
                           1.f, grad_beta};
     rp.job[1] = ReduceJob{(const float*)(ws + w.off_p1), dB, ones_ok ? dbias : nullptr, (int64_t)d_out, d_out,
-                          (d_out + 63) / 64 * 64, r_live, 1, ones_ok ? 63 : -1, scale, grad_beta};
+                          (d_out + 63) / 64 * 64, r_live, 1, ones_ok ? 63 : -1, 1.f /* h_save is already scaled */, grad_beta};
     rc = launch_tn_reduce(rp, dtype, stream);
     if (rc) return rc;
     if (dbias && !ones_ok) {

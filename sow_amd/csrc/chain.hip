@@ -3,7 +3,7 @@
 // One kernel serves both directions of SoWLinear (reference: tn_gradient/layer/sow.py:107-126 and
 // the autograd backward of it):
 //   forward  (BWD=false): X = x [T,d_in],  F1 = A stored [d_in, r] (k-major),
-//                         F2 = B stored [r, d_out];  H = x.A saved UNscaled (for dB).
+//                         F2 = B stored [r, d_out];  H = s*x.A saved (for dB).
 //   backward (BWD=true):  X = dY [T,d_out], F1 = B^T given as stored [r, d_out],
 //                         F2 = A^T given as stored [d_in, r];  H = s*dY.B^T saved (for dA).
 // The live factors are scaled by `scale` (sow.py:117-121); a frozen low-rank accumulator (never scaled,
@@ -17,6 +17,8 @@
 //            the wave-private scratch epilogue as 16-byte row segments.
 // X is read once, Y written once (plus one read when beta != 0); H never round-trips HBM inside
 // the kernel.  Bound: HBM.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 #include "epilogue.hpp"
 
@@ -265,7 +267,10 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainParams p) {
       else
         *(bf16_t*)(Hs + bf16_img_off<CH_RP>(row, c >> 3) + (c & 7) * 2) = (bf16_t)hsc;
       if (Hsave && m0 + row < p.M) {
-        const float sv = live ? (p.save_scaled ? hsc : hu) : 0.f;
+        // live columns, zero padding, and 1.0 in column 63 (when free): the skinny-TN kernel turns that
+        // column into the column sums of its other operand (dbias) at no cost
+        float sv = live ? hsc : 0.f;  // saved SCALED (fwd: s*x.A, so dB = hsave^T dY needs no further scale)
+        if (c == CH_RP - 1 && rtot < CH_RP) sv = 1.f;
         Hsave[(m0 + row) * CH_RP + hc] = from_f32<T>(sv);
       }
     }
@@ -411,6 +416,10 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream) {
   if (!p.X || !p.Y) return SOW_ERR_NULL;
   if (p.ra != 0 || p.rb <= 0 || p.rb > CH_RP) return SOW_ERR_SHAPE;
   if (!p.F1b || !p.F2b) return SOW_ERR_NULL;
+  if (chain2_supported(p, dtype) && !getenv("SOW_AMD_FORCE_CHAIN_V1")) {
+    const int rc = launch_chain2(p, bwd, stream);
+    if (rc != SOW_ERR_ALIGN) return rc;  // factor alignment not met: fall through to the generic kernel
+  }
   const int ve = dtype == SOW_F32 ? 4 : 8;
   const bool vec = p.D1 % ve == 0 && p.D2 % ve == 0 && p.ldx % ve == 0 && p.ldy % ve == 0 && aligned16(p.X) &&
                    aligned16(p.Y) && (!p.bias || aligned16(p.bias));

@@ -17,6 +17,9 @@ struct ChainParams {
   int fast_factors;
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
+// chain2.hip (bf16 streaming version)
+bool chain2_supported(const ChainParams& p, int dtype);
+int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream);
 // skinny_tn.hip
 struct TnJob {
   const void* M;
@@ -27,6 +30,7 @@ struct TnJob {
   int ones_col;
   int ncg;
   int vec;
+  int ones_col_in_s;  // S already carries 1.0 in column `ones_col` (or ones_col < 0): the DMA path cannot patch it
 };
 struct TnParams {
   TnJob job[2];

@@ -185,6 +185,173 @@ template <typename T> __global__ __launch_bounds__(256, 2) void tn_partial_kerne
   for (int reg = 0; reg < 16; ++reg) P[(dm * 32 + acc_row(reg, lane)) * 64 + rn * 32 + li] = acc[reg];
 }
 
+// =================================================================================================
+// bf16 fast path: wave-private LDS-DMA rings + transposed LDS reads (gfx950).
+//
+// Each of the 4 waves streams its own 16-token groups (group g of the slab goes to wave g % 4, so the
+// workgroup as a whole reads contiguous memory): per group two 1-KiB `global_load_lds_dwordx4`
+// instructions for the M rows (16 tokens x 64 columns) and two for the S rows, straight into the
+// wave's ring slot -- no VGPR staging, no workgroup barrier, DEPTH groups in flight per wave
+// (counted s_waitcnt vmcnt).  The tiles stay in their natural [token][column] layout; the MFMA
+// operands need the contraction index (token) down the register, which `ds_read_b64_tr_b16`
+// delivers (4 tokens x 16 columns per 16-lane group, verified by tools/probe.hip).  A 16-byte-chunk
+// XOR (chunk ^ 4*((row>>1)&1)), applied on the DMA source address and again on the read address,
+// spreads the four rows of a transposed read over all 64 banks.
+// Every wave accumulates the full 64x64 tile over its groups; the 4 wave partials are summed
+// through LDS once per slab.
+// =================================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];  // source of out-of-range DMA lanes
+
+constexpr int TN_DEPTH = 4;                 // 16-token groups in flight per wave
+constexpr int TN_STAGE_BYTES = 4096;        // [16][64] bf16 M tile + [16][64] bf16 S tile
+
+__device__ __forceinline__ void tn_wait_stages(int newer) {
+  // wait until all but the `newer` most recent stages (4 DMA instructions each) have landed
+  switch (newer) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void tn_partial_dma_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // wave id as a scalar: keeps the pipeline control flow uniform
+  int b = blockIdx.x, jid = 0;
+  if (p.njobs > 1 && b >= p.job[0].ncg * p.ns) {
+    b -= p.job[0].ncg * p.ns;
+    jid = 1;
+  }
+  // copy the job into scalars once (a reference into the kernel-argument block with a runtime index
+  // makes the compiler re-load it inside the loop)
+  const bf16_t* Mg = (const bf16_t*)(jid ? p.job[1].M : p.job[0].M);
+  const bf16_t* Sg = (const bf16_t*)(jid ? p.job[1].S : p.job[0].S);
+  float* Pg = jid ? p.job[1].partial : p.job[0].partial;
+  const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
+  const int D = jid ? p.job[1].D : p.job[0].D;
+  const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
+  const int cg = b / p.ns, slab = b % p.ns;
+  const int d0 = cg * TN_BD;
+  const int64_t t_begin = (int64_t)slab * p.slab_len;
+  int64_t t_end = t_begin + p.slab_len;
+  if (t_end > p.T) t_end = p.T;
+  char* ring = smem + w * (TN_DEPTH * TN_STAGE_BYTES);
+
+  const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 15) / 16) : 0;
+  const int nw = ngroups > w ? (ngroups - w + 3) / 4 : 0;  // groups of this wave
+
+  // DMA lane geometry: lane -> (row in 8-row block, physical 16-byte chunk); logical chunk un-swizzled
+  const int drow = lane >> 3, dpc = lane & 7;
+  auto issue = [&](int i) {  // i-th group of this wave -> ring slot i % DEPTH
+    const int64_t tt0 = t_begin + (int64_t)(w + 4 * i) * 16;
+    char* slot = ring + (i % TN_DEPTH) * TN_STAGE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = half * 8 + drow;
+      const int lc = dpc ^ (((row >> 1) & 1) << 2);
+      const int64_t tt = tt0 + row;
+      const int dcol = d0 + lc * 8;
+      const void* srcM = (tt < t_end && dcol < D) ? (const void*)(Mg + tt * ldm + dcol) : (const void*)(g_zero_page + (lane & 7) * 4);
+      const void* srcS = (tt < t_end) ? (const void*)(Sg + tt * 64 + lc * 8) : (const void*)(g_zero_page + (lane & 7) * 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcM,
+                                       (__attribute__((address_space(3))) void*)(slot + half * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcS,
+                                       (__attribute__((address_space(3))) void*)(slot + 2048 + half * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+
+  // transposed-read lane geometry (see header): group g = lane>>4, q = row inside the 4-row block,
+  // pp = 4-column piece; h = k half of the MFMA operand
+  const int g = lane >> 4, jj = lane & 15, q = jj >> 2, pp = jj & 3, h = g >> 1;
+  int roff[2][2];  // [tile (0,1)][read (rows 8h+q, 8h+4+q)] byte offset inside a [16][64] bf16 tile
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = 8 * h + 4 * rd + q;
+      const int col = tile * 32 + 16 * (g & 1) + 4 * pp;
+      const int pc = (col >> 3) ^ (((row >> 1) & 1) << 2);
+      roff[tile][rd] = row * 128 + pc * 16 + (col & 7) * 2;
+    }
+
+  // LDS byte addresses for the inline-asm transposed reads.  The reads are inline asm on purpose:
+  // for a compiler-visible LDS read hipcc inserts `s_waitcnt vmcnt(0)` (LDS-DMA may alias), which
+  // would drain the ring every step; here the counted vmcnt above is the only DMA wait.
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  const int pre = nw < TN_DEPTH ? nw : TN_DEPTH;
+  for (int i = 0; i < pre; ++i) issue(i);
+  for (int i = 0; i < nw; ++i) {
+    const int newer = (nw - 1 - i) < (TN_DEPTH - 1) ? (nw - 1 - i) : (TN_DEPTH - 1);
+    tn_wait_stages(newer);
+    const uint32_t slot_addr = ring_addr + (uint32_t)((i % TN_DEPTH) * TN_STAGE_BYTES);
+    const uint32_t ad0 = slot_addr + (uint32_t)roff[0][0], ad1 = slot_addr + (uint32_t)roff[1][0];
+    u32x2 a00, a01, a10, a11, b00, b01, b10, b11;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:512\n\t"
+        "ds_read_b64_tr_b16 %2, %9\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:512\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:2560\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:2048\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:2560\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(a00), "=&v"(a01), "=&v"(a10), "=&v"(a11), "=&v"(b00), "=&v"(b01), "=&v"(b10), "=&v"(b11)
+        : "v"(ad0), "v"(ad1)
+        : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 af[2], bfr[2];
+    af[0] = __builtin_bit_cast(bf16x8, (u32x4){a00[0], a00[1], a01[0], a01[1]});
+    af[1] = __builtin_bit_cast(bf16x8, (u32x4){a10[0], a10[1], a11[0], a11[1]});
+    bfr[0] = __builtin_bit_cast(bf16x8, (u32x4){b00[0], b00[1], b01[0], b01[1]});
+    bfr[1] = __builtin_bit_cast(bf16x8, (u32x4){b10[0], b10[1], b11[0], b11[1]});
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][c] = mfma32(af[a], bfr[c], acc[a][c]);
+    // the slot's reads have returned (lgkmcnt(0) inside the asm), so it may be refilled now
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + TN_DEPTH < nw) issue(i + TN_DEPTH);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // cross-wave sum of the four [64][64] fp32 partials through LDS (aliases the rings), then one
+  // coalesced 16-byte store per thread-quad row to partial[slab][d0 + row][col]
+  float* red = (float*)smem;  // [4 waves][64][64]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        red[w * 4096 + (a * 32 + acc_row(reg, lane)) * 64 + c * 32 + (lane & 31)] = acc[a][c][reg];
+  __syncthreads();
+  float* P = Pg + ((int64_t)slab * ncg * TN_BD + d0) * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = t + 256 * it;  // 1024 float4 of the [64][64] tile
+    f32x4 s0 = *(const f32x4*)(red + v * 4);
+    const f32x4 s1 = *(const f32x4*)(red + 4096 + v * 4);
+    const f32x4 s2 = *(const f32x4*)(red + 8192 + v * 4);
+    const f32x4 s3 = *(const f32x4*)(red + 12288 + v * 4);
+    s0 = (s0 + s1) + (s2 + s3);
+    *(f32x4*)(P + v * 4) = s0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic slab reduction + crop + optional transpose + cast.
 //   out[d][r]   (transpose = 0, ld = out_ld)   or   out[r][d]   (transpose = 1)
@@ -198,16 +365,27 @@ template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(co
     jid = 1;
   }
   const ReduceJob& J = p.job[jid];
-  // one thread per (d, 4 consecutive columns): 16 threads per row, 16 rows per block
-  const int d = b * 16 + (threadIdx.x >> 4);
-  const int c4 = (threadIdx.x & 15) * 4;
-  if (d >= J.D) return;
+  // 256 threads = 4 slab splits x 4 rows x 16 column quads; splits are summed through LDS in a fixed
+  // order, so the result does not depend on scheduling
+  __shared__ f32x4 red[4][64];
+  const int split = threadIdx.x >> 6, rl = (threadIdx.x >> 4) & 3, cq = threadIdx.x & 15;
+  const int d = b * 4 + rl;
+  const int c4 = cq * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const int64_t stride = (int64_t)J.Dpad * 64;
-  const float* src = J.partial + (int64_t)d * 64 + c4;
-  for (int i = 0; i < p.ns; ++i) {
-    const f32x4 v = *(const f32x4*)(src + i * stride);
-    s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+  if (d < J.D) {
+    const int64_t stride = (int64_t)J.Dpad * 64;
+    const float* src = J.partial + (int64_t)d * 64 + c4;
+    for (int i = split; i < p.ns; i += 4) {
+      const f32x4 v = *(const f32x4*)(src + i * stride);
+      s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+    }
+  }
+  red[split][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (split != 0 || d >= J.D) return;
+  {
+    const f32x4 s1 = red[1][threadIdx.x], s2 = red[2][threadIdx.x], s3 = red[3][threadIdx.x];
+    s = (s + s1) + (s2 + s3);
   }
   T* out = (T*)J.out;
 #pragma unroll
@@ -254,9 +432,25 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
   int blocks = 0;
   for (int j = 0; j < p.njobs; ++j) blocks += p.job[j].ncg * p.ns;
   if (blocks == 0) return SOW_OK;
-  if (dtype == SOW_BF16)
-    hipLaunchKernelGGL(tn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
-  else if (dtype == SOW_F32)
+  if (dtype == SOW_BF16) {
+    bool dma = p.slab_len % 16 == 0;
+    for (int j = 0; j < p.njobs; ++j) {
+      const TnJob& J = p.job[j];
+      dma = dma && J.D % 8 == 0 && J.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
+    }
+    if (dma) {
+      constexpr int LDS = 4 * TN_DEPTH * TN_STAGE_BYTES;  // 64 KiB (rings; reused by the cross-wave sum)
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tn_partial_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(tn_partial_dma_kernel, dim3(blocks), dim3(256), LDS, stream, p);
+    } else {
+      hipLaunchKernelGGL(tn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
+    }
+  } else if (dtype == SOW_F32)
     hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
   else
     return SOW_ERR_DTYPE;
@@ -265,9 +459,9 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
 }
 
 int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream) {
-  p.blocks0 = (p.job[0].D + 15) / 16;
+  p.blocks0 = (p.job[0].D + 3) / 4;
   int blocks = p.blocks0;
-  if (p.njobs > 1) blocks += (p.job[1].D + 15) / 16;
+  if (p.njobs > 1) blocks += (p.job[1].D + 3) / 4;
   if (blocks == 0) return SOW_OK;
   if (dtype == SOW_BF16)
     hipLaunchKernelGGL(tn_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);

@@ -71,6 +71,11 @@ SHAPES = [
     (257, 100, 36, 70, "dense", True),        # r > 64: GEMM composition path
     (90, 50, 70, 7, "lowrank", False),        # odd everything: scalar paths
     (200, 128, 64, 16, "lowrank_big", False), # low-rank accumulator wider than 64
+    # T >= 4096 takes the bf16 streaming kernels (chain2: LDS-DMA rings + loader wave + transposed reads)
+    (4100, 512, 1376, 50, None, True),        # ragged token tail, partial last factor chunk (1376 = 5.375 * 256)
+    (4224, 1376, 512, 50, "dense", False),    # beta = 1 epilogue on top of the dense-accumulator GEMM
+    (4096, 768, 768, 8, None, False),         # rank 8 (one MFMA k-step), north-star width
+    (5000, 264, 72, 50, "lowrank", True),     # widths that are not multiples of 64
 ]
 
 
