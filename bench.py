@@ -26,6 +26,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+# WRITE_SIZE, see profiles/); None until collected for the current kernel version.
+TRAFFIC_BYTES_PER_LAUNCH = 98.2e6  # profiles/r01_pmc_hbm_fetch_write.txt (bf16, chain2_kernel<false>)
 LLAMA_60M = dict(hidden=512, inter=1376, layers=8)
 
 
@@ -195,26 +198,26 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
 
-        # per-kernel-group timing with HIP events on the launch stream (rank 0, after the timed region)
+        # per-kernel timing with HIP events on the launch stream (rank 0, after the timed region).
+        # forward_all launches exactly one kernel per layer (chain2_kernel<false>), so its average is a
+        # single-kernel figure that can be checked against the rocprofv3 stats under profiles/.
         groups = {}
         if rank == 0:
             it = max(3, min(args.steps, 10))
-            groups["forward (chain_kernel fwd x56)"] = time_region(stack.forward_all, it, stream)
-            groups["backward (chain_kernel bwd + tn_partial + tn_reduce, x56 each)"] = time_region(stack.backward_all, it, stream)
+            groups["forward: chain kernel x56"] = time_region(stack.forward_all, it, stream)
+            groups["backward: chain kernel + tn_partial + tn_reduce, x56 each"] = time_region(stack.backward_all, it, stream)
 
     ms = elapsed / args.steps * 1e3
     flops, nbytes = algorithmic(shapes, T, args.rank, es, args.acc)
     if rank == 0:
         n_layers = len(shapes)
-        fwd_ms = groups["forward (chain_kernel fwd x56)"]
-        fwd_bytes = sum(T * (di + do) * es + T * args.rank * es for di, do in shapes)
-        bwd_ms = groups["backward (chain_kernel bwd + tn_partial + tn_reduce, x56 each)"]
-        bwd_bytes = nbytes - fwd_bytes
-        # dominant group = the one with the larger time share; the roofline line prices it per launch set
-        if bwd_ms >= fwd_ms:
-            kname, kms, kbytes = "backward set (chain bwd + skinny-TN + reduce) per layer", bwd_ms / n_layers, bwd_bytes / n_layers
-        else:
-            kname, kms, kbytes = "chain_kernel<bf16,fwd> per layer", fwd_ms / n_layers, fwd_bytes / n_layers
+        fwd_ms = groups["forward: chain kernel x56"]
+        # dominant kernel (largest total time in profiles/r01_bench_v2_kernel_stats.csv): the forward chain
+        # kernel.  Algorithmic bytes per launch = T*(d_in + d_out + r)*s averaged over the 56 layers
+        # (x read once, y written once, h saved once).
+        kname = "sow::chain2_kernel<false> (fused forward chain)" if args.dtype == "bf16" else "sow::chain_kernel<float, fwd>"
+        kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / n_layers
+        kms = fwd_ms / n_layers
         achieved = kbytes / (kms * 1e-3) / 1e9
         out = {
             "metric": "SoWLinear fwd+bwd tokens/s, llama_60m rank=50 (56-layer SoWLinear stack)",
@@ -236,7 +239,7 @@ def main():
             "algorithmic_gbytes_per_step": nbytes / 1e9,
             "step_hbm_gbs": nbytes / (ms * 1e-3) / 1e9,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (args.dtype == "bf16" and args.acc == "none") else None,
                          "avg_launch_ms": kms, "algorithmic_bytes_per_launch": kbytes},
             "kernel_groups_ms": groups,
         }
