@@ -15,8 +15,9 @@
 //     overlap"); the garbage lands in rank columns >= r, which always meet an explicit zero (rows >= r of
 //     B come from a zero page, H columns >= r are masked), so it never reaches a result.  The last row of
 //     A, whose tail would cross the end of the buffer, is rewritten by the loader from a guarded load.
-// Workgroup = 8 waves: compute waves 0-3 (32 tokens each, 128 per workgroup), loader waves 4-7.
-// One raw s_barrier per chunk hands chunk c to the consumers and frees slot (c-2) % 8 for the loader.
+// Workgroup = 4 waves: compute waves 0-1 (32 tokens each, 64 per workgroup), loader waves 2-3; 80 KiB of
+// LDS, so two workgroups share a CU and are staggered by one phase (see the kernel body).
+// One raw s_barrier per chunk hands chunk c to the consumers and frees slot (c-2) % 4 for the loader.
 // Per compute wave: phase 1 accumulates H[32,64] over K; H is scaled, rounded and parked in the
 // wave's own LDS (it leaves the CU only as the saved copy for backward); phase 2 produces Y in
 // 64-column slices written as 16-byte row segments.
@@ -31,18 +32,25 @@
 
 #include "kernels.hpp"
 
+#ifndef SOW_CHAIN2_DIAG
+#define SOW_CHAIN2_DIAG 0   // 1: honour SOW_AMD_CHAIN2_DEBUG / _DBGBUF (timing experiments, tools/chain_*.py)
+#endif
+
 namespace sow {
 
-constexpr int C2_BM = 128;            // tokens per workgroup
-constexpr int C2_DEPTH = 6;           // X stages in flight per compute wave (6 x 4 KiB x 4 waves + 64 KiB factor ring = 160 KiB)
+constexpr int C2_NCW = 2;             // compute waves per workgroup (32 tokens each)
+constexpr int C2_NLW = 2;             // loader waves per workgroup
+constexpr int C2_BM = 32 * C2_NCW;    // tokens per workgroup
+constexpr int C2_DEPTH = 6;           // X stages in flight per compute wave
 constexpr int C2_STAGE = 4096;        // [32 tok][64 k] bf16
-constexpr int C2_NSLOT = 8;           // factor chunk slots
-constexpr int C2_AHEAD = 6;           // chunks the loaders run ahead
+constexpr int C2_NSLOT = 4;           // factor chunk slots
+constexpr int C2_AHEAD = 2;           // chunks the loaders run ahead (slot c+AHEAD held chunk c+AHEAD-NSLOT <= c-2)
 constexpr int C2_FSLOT = 8192;        // [64][64] bf16
+constexpr int C2_LPW = 8 / C2_NLW;    // 1-KiB DMA instructions per loader wave per chunk
 constexpr int C2_RING0 = C2_NSLOT * C2_FSLOT;
-constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 16 KiB per compute wave
-constexpr int C2_LDS = C2_RING0 + 4 * C2_RING;
-constexpr int C2_THREADS = 512;
+constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 24 KiB per compute wave
+constexpr int C2_LDS = C2_RING0 + C2_NCW * C2_RING;   // 80 KiB: two workgroups per CU
+constexpr int C2_THREADS = 64 * (C2_NCW + C2_NLW);
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page2[64];
 
@@ -90,20 +98,25 @@ template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
 // =================================================================================================
 // BWD = false: forward  (F1 = A [D1, r] rows = k, F2 = B [r, D2] rows = k  -> transposed reads)
 // BWD = true : backward (F1 = B [r, D1] rows = rank, F2 = A [D2, r] rows = n -> b128 reads)
-template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kernel(const ChainParams p) {
+template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 2) void chain2_kernel(const ChainParams p) {
   constexpr bool TR = !BWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t m0 = (int64_t)blockIdx.x * C2_BM;
   const int D1 = p.D1, D2 = p.D2, rb = p.rb;
+  const int dflags = SOW_CHAIN2_DIAG ? p.fast_factors : 0;   // diagnostics only; constant 0 in production
   // diagnostic timeline (SOW_AMD_CHAIN2_DEBUG bit 32 + SOW_AMD_CHAIN2_DBGBUF): never set in production
-  unsigned long long* tl_buf = (p.fast_factors & 32) ? (unsigned long long*)p.F1a + ((int64_t)blockIdx.x * 8 + w) * 16 : nullptr;
+  unsigned long long* tl_buf = (dflags & 32) ? (unsigned long long*)p.F1a + ((int64_t)blockIdx.x * 4 + w) * 16 : nullptr;
   unsigned long long t_wait = 0, t_mark = 0;
   auto stamp = [&](int slot) {
     if (tl_buf && lane == 0) tl_buf[slot] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
+  if (tl_buf && lane == 0) {
+    tl_buf[10] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+    tl_buf[11] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+  }
   const int nst = (D1 + 63) / 64;   // phase-1 chunks = X stages
   const int nsl = (D2 + 63) / 64;   // phase-2 chunks = output slices
   const int total = nst + nsl;
@@ -112,14 +125,22 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
   const int64_t ldb = BWD ? p.ldf1b : p.ldf2b;
   const int rows_a = BWD ? D2 : D1, cols_b = BWD ? D1 : D2;
 
-  if (w >= 4) {
+  // Stagger: the two workgroups that share a CU (ids b and b + grid/2 under round-robin placement; only
+  // speed depends on that, never correctness) should be half a kernel apart, so that one streams X in
+  // while the other streams Y out.  The second half of the grid sleeps for about one phase-1 duration:
+  // its X bytes at the CU's fair share of HBM bandwidth (~10 B/clk).
+  if ((dflags & 64) && 2 * blockIdx.x >= gridDim.x) {   // measured: no gain (per-wave issue-bound), off by default
+    const unsigned long long t_go = __builtin_amdgcn_s_memtime() + (unsigned long long)(C2_BM * D1 * 2) / 10u;
+    while (__builtin_amdgcn_s_memtime() < t_go) __builtin_amdgcn_s_sleep(8);
+  }
+  if (w >= C2_NCW) {
     // ------------------------------------------------------------------ loader waves
-    const int lw = w - 4;
+    const int lw = w - C2_NCW;
     const char* a_end = (const char*)(Amat + (int64_t)rows_a * rb);
     // the last row of A, kept in a register for the fix-up by the loader wave that DMAs that row
     // (rows 16*lw .. 16*lw+15 of a chunk belong to loader wave lw, so its own counted wait orders the
     // fix-up after its DMA)
-    const bool own_last = lw == ((rows_a - 1) & 63) >> 4;
+    const bool own_last = lw == ((rows_a - 1) & 63) / (8 * C2_LPW);
     uint32_t last_row_dw = 0u;
     if (own_last && lane < 32 && 2 * lane < rb) last_row_dw = *((const uint32_t*)(Amat + (int64_t)(rows_a - 1) * rb) + lane);
     asm volatile("" : "+v"(last_row_dw));  // consume now: the compiler's wait for this load lands here, not mid-pipeline
@@ -127,12 +148,12 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
     // per-lane source pointers of chunk 0, advanced by a constant per chunk (address arithmetic is the
     // loaders' critical path at one wave per SIMD, so it is hoisted out of the loop)
     const char* zp = (const char*)(g_zero_page2 + (lane & 7) * 4);
-    const char* a_ptr[2];
-    const char* b_ptr[2];
-    int b_stride[2], b_lc[2];
+    const char* a_ptr[C2_LPW];
+    const char* b_ptr[C2_LPW];
+    int b_stride[C2_LPW], b_lc[C2_LPW];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int i = 2 * lw + ii;
+    for (int ii = 0; ii < C2_LPW; ++ii) {
+      const int i = C2_LPW * lw + ii;
       const int row = 8 * i + (lane >> 3), pc = lane & 7;
       const int lc = img_chunk<TR>(row, pc);
       a_ptr[ii] = (const char*)(Amat + (int64_t)row * rb) + 16 * lc;
@@ -145,23 +166,23 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
     const bool b_ragged = (cols_b & 63) != 0;
     const int nb_chunks = (cols_b + 63) / 64;
     auto issue = [&](int c) {
-      if (p.fast_factors & 8) return;   // timing experiment: no factor DMA
+      if (dflags & 8) return;   // timing experiment: no factor DMA
       char* slot = smem + (c % C2_NSLOT) * C2_FSLOT;
       const int ci = c < nst ? c : c - nst;   // chunk index inside its matrix
       if (chunk_is_a(c)) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < C2_LPW; ++ii) {
           // A rows: 2*rb bytes each, read as 128-byte rows (tail = head of the next row); pieces that
           // would cross the end of the buffer read zeros (the last row is rewritten by the fix-up)
           const char* q = a_ptr[ii] + (int64_t)ci * a_chunk_bytes;
-          dma16(q + 16 <= a_end ? (const void*)q : (const void*)zp, slot + (2 * lw + ii) * 1024);
+          dma16(q + 16 <= a_end ? (const void*)q : (const void*)zp, slot + (C2_LPW * lw + ii) * 1024);
         }
       } else {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < C2_LPW; ++ii) {
           const char* q = b_ptr[ii] + ci * b_stride[ii];
           if (b_ragged && ci == nb_chunks - 1 && ci * 64 + 8 * b_lc[ii] >= cols_b) q = zp;
-          dma16((const void*)q, slot + (2 * lw + ii) * 1024);
+          dma16((const void*)q, slot + (C2_LPW * lw + ii) * 1024);
         }
       }
     };
@@ -171,7 +192,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
     for (int c = 0; c < total; ++c) {
       const int newer = (total - 1 - c) < (C2_AHEAD - 1) ? (total - 1 - c) : (C2_AHEAD - 1);
       if (tl_buf) t_mark = __builtin_amdgcn_s_memtime();
-      if (!(p.fast_factors & 8)) wait_groups<2>(newer);
+      if (!(dflags & 8)) wait_groups<C2_LPW>(newer);
       if (tl_buf) t_wait += __builtin_amdgcn_s_memtime() - t_mark;
       if (c == nst) stamp(2);
       // fix-up: rewrite the last row of A (its DMA pieces past the end of the buffer were zero-filled)
@@ -330,7 +351,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
   auto step1 = [&](int st, Frags& cur, Frags& nxt) {
     if (st + 1 < nst) wait_stage(st + 1, C2_DEPTH - 2);   // X(st+DEPTH) is issued at the END of this step
     LGKM_WAIT0();                                   // reads(st) have returned
-    if (p.fast_factors & 16) {                       // timing experiment: barriers + X DMA only
+    if (dflags & 16) {                       // timing experiment: barriers + X DMA only
       if (st + C2_DEPTH < nst) issue_x(st + C2_DEPTH);
       return;
     }
@@ -349,7 +370,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
   {
     Frags FA, FB;
     wait_stage(0, C2_DEPTH - 1);
-    if (!(p.fast_factors & 16)) issue_reads_p1(0, FA);
+    if (!(dflags & 16)) issue_reads_p1(0, FA);
     int st = 0;
 #pragma unroll 1
     for (; st + 1 < nst; st += 2) {
@@ -361,7 +382,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 1) void chain2_kern
 
   stamp(2);
   if (tl_buf && lane == 0) tl_buf[8] = t_wait, tl_buf[9] = t_bar;
-  const int dbg = p.fast_factors;  // timing experiments only (SOW_AMD_CHAIN2_DEBUG); 0 in production
+  const int dbg = dflags;
   // ================================================================== hand-off (registers only)
   // scale, mask rank rows >= r (overlap garbage / zeros), round to bf16: hf[s] is the phase-2 B operand
   // of k-step s; the same values go to the saved copy [M, 64] as 8-byte row pieces.
@@ -507,12 +528,15 @@ bool chain2_supported(const ChainParams& p, int dtype) {
 
 int launch_chain2(const ChainParams& p_in, bool bwd, hipStream_t stream) {
   ChainParams p = p_in;
+  p.fast_factors = 0;
+#if SOW_CHAIN2_DIAG
   {
     const char* e = getenv("SOW_AMD_CHAIN2_DEBUG");
     p.fast_factors = e ? atoi(e) : 0;
     const char* b = getenv("SOW_AMD_CHAIN2_DBGBUF");
     if ((p.fast_factors & 32) && b) p.F1a = (const void*)strtoull(b, nullptr, 0); else p.fast_factors &= ~32;
   }
+#endif
   // B is DMA'd in aligned 16-byte pieces along its rows; A must be contiguous [rows, r] and 4-byte aligned
   const void* Bp = bwd ? p.F1b : p.F2b;
   const int64_t ldB = bwd ? p.ldf1b : p.ldf2b;
