@@ -49,15 +49,25 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--acc", default="none", choices=["none", "dense"], help="accumulator state of the layers")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: weight-gradient kernels on a side stream (measured: no gain, the kernels are HBM-bound)")
     return ap.parse_args()
 
 
 class Stack:
     """The 56-layer SoWLinear stack with resident synthetic inputs."""
 
-    def __init__(self, shapes, T, r, dtype, device, acc):
+    def __init__(self, shapes, T, r, dtype, device, acc, streams=1):
+        from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
+        self.streams = streams
+        self.side = torch.cuda.Stream(device=device) if streams > 1 else None
+        kind = 2 if acc == "dense" else 0
+        # per-layer workspaces (dh + slab partials): the split backward keeps them alive across two streams
+        self.ws = [torch.empty(ops.workspace_bytes(T, di, do, r, 0, kind, dtype) + 256, dtype=torch.uint8, device=device)
+                   for di, do in shapes]
+        self.dx = {di: [torch.empty(T, di, dtype=dtype, device=device) for _ in range(4)] for di in {s[0] for s in shapes}}
         g = torch.Generator(device=device)
         self.x, self.dy, self.A, self.B, self.W = [], [], [], [], []
         params = []
@@ -80,10 +90,29 @@ class Stack:
             _, self.h[li] = ops.sow_forward(self.x[li], self.A[li].data, self.B[li].data, self.W[li], None, None, 1.0)
 
     def backward_all(self):
-        from sow_amd import ops
-        for li in reversed(range(len(self.shapes))):
-            ops.sow_backward(self.dy[li], self.x[li], self.h[li], self.A[li].data, self.B[li].data, self.W[li], None, 1.0,
-                             False, out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0)
+        """Backward in reverse layer order.  The data-gradient kernel of a layer (dX: what the previous
+        layer's backward waits for in a real model) stays on the main stream; with --streams 2 the
+        weight-gradient kernels (skinny-TN + reduce), which nothing in backprop depends on, run on a side
+        stream ordered by an event -- the true dependency structure of a training step."""
+        from sow_amd import _lib, ops
+        main = torch.cuda.current_stream()
+        if self.side is not None:
+            self.side.wait_stream(main)
+        for n, li in enumerate(reversed(range(len(self.shapes)))):
+            args = (self.dy[li], self.x[li], self.h[li], self.A[li].data, self.B[li].data, self.W[li], None, 1.0, False)
+            kw = dict(out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0, workspace=self.ws[li],
+                      dx=self.dx[self.shapes[li][0]][n % 4])
+            if self.side is None:
+                ops.sow_backward(*args, **kw)
+            else:
+                ops.sow_backward(*args, phases=_lib.BWD_DATA, **kw)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    ops.sow_backward(*args, phases=_lib.BWD_WEIGHTS, **kw)
+        if self.side is not None:
+            main.wait_stream(self.side)
 
     def step(self):
         self.forward_all()
@@ -153,7 +182,7 @@ def main():
 
     from sow_amd import _lib
     _lib.load()  # fail loudly when the HIP library is missing
-    stack = Stack(shapes, T, args.rank, dtype, device, args.acc)
+    stack = Stack(shapes, T, args.rank, dtype, device, args.acc, args.streams)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
 
@@ -234,7 +263,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
-                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None},
+                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None, "streams": args.streams},
             "gflops": flops * world / (ms * 1e-3) / 1e9,
             "algorithmic_gbytes_per_step": nbytes / 1e9,
             "step_hbm_gbs": nbytes / (ms * 1e-3) / 1e9,

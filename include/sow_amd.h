@@ -76,6 +76,19 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
                  int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* The same in two phases, so that the weight-gradient kernels (off the critical path of backpropagation)
+ * can run on another stream than the data-gradient kernel:
+ *   SOW_BWD_DATA    : dX and the internal dh = scale * dY @ B^T (kept in `workspace`)
+ *   SOW_BWD_WEIGHTS : dA, dB, dbias from x, dY, h_save and the dh left in the SAME workspace by a
+ *                     preceding SOW_BWD_DATA call (the caller orders the two calls, e.g. with an event).
+ * phases = SOW_BWD_DATA | SOW_BWD_WEIGHTS is sow_backward. */
+#define SOW_BWD_DATA 1
+#define SOW_BWD_WEIGHTS 2
+int sow_backward_ex(const void* dy, const void* x, const void* h_save, const void* A, const void* B,
+                    const void* acc_down, const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T,
+                    int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype,
+                    void* workspace, size_t workspace_bytes, int phases, void* stream);
+
 /* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
  * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call
  * sites: accumulate() sow.py:131-140 (W_acc += scale * A @ B, Q @ R), prepare.py:135, tt.py:213-237. */
@@ -107,6 +120,12 @@ int sow_ttadam_dense(float* param, const float* grad, float* exp_avg, float* exp
 /* TT Hadamard product of two cores (tt.py:469-475): out[(a,c),ij,(b,d)] = A[a,ij,b] * B[c,ij,d], fp32. */
 int sow_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
                      void* stream);
+
+/* out[0] = max |x[i]| over n fp32 elements (TensorTrain.sqrt / sqrtinv scaling, tt.py:288, 322). */
+int sow_absmax(const float* x, int64_t n, float* out, void* stream);
+
+/* Batched inverse of `batch` small [r, r] fp32 matrices, r <= 16 (TensorTrain.reciprocal, tt.py:480-494). */
+int sow_small_inverse(const float* A, float* out, int batch, int r, void* stream);
 
 /* y = a*x + b*y over n elements. */
 int sow_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream);

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsow_amd.so")
 F32, BF16 = 0, 1
 ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2
 H_COLS = 64
+BWD_DATA, BWD_WEIGHTS = 1, 2
 
 # name -> (restype, argtypes); mirrors include/sow_amd.h one to one
 SIGNATURES = {
@@ -27,6 +28,8 @@ SIGNATURES = {
                                                c_size_t, c_void_p]),
     "sow_backward": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                                  c_void_p, c_size_t, c_void_p]),
+    "sow_backward_ex": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                    c_void_p, c_size_t, c_int, c_void_p]),
     "sow_gemm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
                          c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "sow_qr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -38,6 +41,8 @@ SIGNATURES = {
     "sow_ttadam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                  c_float, c_int, c_void_p]),
     "sow_tt_kron_core": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sow_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "sow_small_inverse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sow_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "sow_cast_copy": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
 }

@@ -139,11 +139,13 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
   return launch_gemm(h_save, r_live, false, B, d_out, false, y, d_out, bias, T, d_out, r_live, scale, beta, dtype, stream);
 }
 
-int sow_backward(const void* dy, const void* x, const void* h_save, const void* A, const void* B, const void* acc_down,
-                 const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out,
-                 int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
-                 size_t workspace_bytes, void* stream_) {
+int sow_backward_ex(const void* dy, const void* x, const void* h_save, const void* A, const void* B, const void* acc_down,
+                    const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out,
+                    int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
+                    size_t workspace_bytes, int phases, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const bool do_data = (phases & SOW_BWD_DATA) != 0, do_weights = (phases & SOW_BWD_WEIGHTS) != 0;
+  if (!do_data && !do_weights) return SOW_ERR_SHAPE;
   if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
   if (T == 0) {
@@ -167,7 +169,9 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
   void* dh = ws + w.off_dh;
   float beta = 0.f;
   int rc;
-  if (acc_kind == SOW_ACC_DENSE) {
+  if (!do_data) {
+    // weights-only call: dh was produced by an earlier SOW_BWD_DATA call on the same workspace
+  } else if (acc_kind == SOW_ACC_DENSE) {
     // dX = dY . W_acc^T   (W_acc stored [d_in, d_out] = [N, K])
     rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
     if (rc) return rc;
@@ -198,8 +202,11 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
     p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
     p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
     p.scale = scale, p.beta = beta, p.save_scaled = 1;
-    rc = launch_chain(p, dtype, true, stream);
-    if (rc) return rc;
+    if (do_data) {
+      rc = launch_chain(p, dtype, true, stream);
+      if (rc) return rc;
+    }
+    if (!do_weights) return SOW_OK;
     // weight gradients: dA = x^T dh ; dB^T = dY^T h ; dbias = colsum(dY) via the all-ones column 63
     const bool ones_ok = dbias && r_live <= 63;
     TnParams tp{};
@@ -232,10 +239,13 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
     return SOW_OK;
   }
   // generic rank (GEMM composition)
-  rc = launch_gemm(dy, d_out, false, B, d_out, true, dh, r_live, nullptr, T, r_live, d_out, scale, 0.f, dtype, stream);
-  if (rc) return rc;
-  rc = launch_gemm(dh, r_live, false, A, r_live, true, dx, d_in, nullptr, T, d_in, r_live, 1.f, beta, dtype, stream);
-  if (rc) return rc;
+  if (do_data) {
+    rc = launch_gemm(dy, d_out, false, B, d_out, true, dh, r_live, nullptr, T, r_live, d_out, scale, 0.f, dtype, stream);
+    if (rc) return rc;
+    rc = launch_gemm(dh, r_live, false, A, r_live, true, dx, d_in, nullptr, T, d_in, r_live, 1.f, beta, dtype, stream);
+    if (rc) return rc;
+  }
+  if (!do_weights) return SOW_OK;
   rc = launch_gemm(x, d_in, true, dh, r_live, false, dA, r_live, nullptr, d_in, r_live, (int)T, 1.f, grad_beta, dtype, stream);
   if (rc) return rc;
   rc = launch_gemm(h_save, r_live, true, dy, d_out, false, dB, d_out, nullptr, r_live, d_out, (int)T, scale, grad_beta, dtype, stream);
@@ -248,6 +258,14 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
     SOW_CHECK_LAUNCH();
   }
   return SOW_OK;
+}
+
+int sow_backward(const void* dy, const void* x, const void* h_save, const void* A, const void* B, const void* acc_down,
+                 const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out,
+                 int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  return sow_backward_ex(dy, x, h_save, A, B, acc_down, acc_up, dx, dA, dB, dbias, T, d_in, d_out, r_live, r_acc, acc_kind,
+                         scale, grad_beta, dtype, workspace, workspace_bytes, SOW_BWD_DATA | SOW_BWD_WEIGHTS, stream);
 }
 
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
@@ -347,6 +365,14 @@ int sow_ttadam_dense(float* param, const float* grad, float* exp_avg, float* exp
 int sow_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
                      void* stream) {
   return launch_tt_kron_core(A, B, out, ra0, rb0, ij, ra1, rb1, (hipStream_t)stream);
+}
+
+int sow_absmax(const float* x, int64_t n, float* out, void* stream) {
+  return launch_absmax(x, n, out, (hipStream_t)stream);
+}
+
+int sow_small_inverse(const float* A, float* out, int batch, int r, void* stream) {
+  return launch_small_inverse(A, out, batch, r, (hipStream_t)stream);
 }
 
 int sow_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, void* stream) {

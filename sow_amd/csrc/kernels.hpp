@@ -77,5 +77,7 @@ int launch_ttadam_dense(float* p, const float* g, float* m, float* v, int64_t n,
                         float step_size, float lr_wd, int clamp_v, hipStream_t stream);
 int launch_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
                         hipStream_t stream);
+int launch_absmax(const float* x, int64_t n, float* out, hipStream_t stream);
+int launch_small_inverse(const float* A, float* out, int batch, int r, hipStream_t stream);
 int launch_axpby(const void* x, void* y, int64_t n, float a, float b, int dtype, hipStream_t stream);
 }  // namespace sow

@@ -166,6 +166,77 @@ int launch_tt_kron_core(const float* A, const float* B, float* out, int ra0, int
   return SOW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// max |x| over a contiguous fp32 buffer (TensorTrain.sqrt / sqrtinv scaling, tt.py:288, 322): one
+// workgroup, result written to out[0]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void absmax_kernel(const float* x, int64_t n, float* out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 16; ++q) m = fmaxf(m, red[q]);
+    out[0] = m;
+  }
+}
+
+int launch_absmax(const float* x, int64_t n, float* out, hipStream_t stream) {
+  if (!x || !out) return SOW_ERR_NULL;
+  if (n < 0) return SOW_ERR_SHAPE;
+  hipLaunchKernelGGL(absmax_kernel, dim3(1), dim3(1024), 0, stream, x, n, out);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched inverse of small [r, r] matrices by Gauss-Jordan with partial pivoting, one thread per matrix
+// (TensorTrain.reciprocal, tt.py:480-494: the middle cores' [:, i, j, :] slices).  In [batch, r, r] fp32.
+// ---------------------------------------------------------------------------------------------
+constexpr int INV_MAX_R = 16;
+__global__ __launch_bounds__(64) void small_inverse_kernel(const float* A, float* out, int batch, int r) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  float a[INV_MAX_R][INV_MAX_R], inv[INV_MAX_R][INV_MAX_R];
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < r; ++j) {
+      a[i][j] = A[((int64_t)b * r + i) * r + j];
+      inv[i][j] = i == j ? 1.f : 0.f;
+    }
+  for (int c = 0; c < r; ++c) {
+    int piv = c;
+    float best = fabsf(a[c][c]);
+    for (int i = c + 1; i < r; ++i)
+      if (fabsf(a[i][c]) > best) best = fabsf(a[i][c]), piv = i;
+    if (piv != c)
+      for (int j = 0; j < r; ++j) {
+        float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t;
+        t = inv[c][j]; inv[c][j] = inv[piv][j]; inv[piv][j] = t;
+      }
+    const float d = 1.f / a[c][c];
+    for (int j = 0; j < r; ++j) a[c][j] *= d, inv[c][j] *= d;
+    for (int i = 0; i < r; ++i) {
+      if (i == c) continue;
+      const float f = a[i][c];
+      for (int j = 0; j < r; ++j) a[i][j] -= f * a[c][j], inv[i][j] -= f * inv[c][j];
+    }
+  }
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < r; ++j) out[((int64_t)b * r + i) * r + j] = inv[i][j];
+}
+
+int launch_small_inverse(const float* A, float* out, int batch, int r, hipStream_t stream) {
+  if (!A || !out) return SOW_ERR_NULL;
+  if (batch < 0 || r < 1 || r > INV_MAX_R) return SOW_ERR_UNSUPPORTED;
+  if (batch == 0) return SOW_OK;
+  hipLaunchKernelGGL(small_inverse_kernel, dim3((batch + 63) / 64), dim3(64), 0, stream, A, out, batch, r);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
 // y = a*x + b*y   (fp32 or bf16)
 template <typename T>
 __global__ __launch_bounds__(256) void axpby_kernel(const T* x, T* y, int64_t n, float a, float b) {

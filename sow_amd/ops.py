@@ -97,11 +97,18 @@ def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, ac
     return y, h
 
 
+def workspace_bytes(T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dtype: torch.dtype) -> int:
+    return _lib.load().sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, _DT[dtype])
+
+
 def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down,
                  acc_up, scale: float, need_bias: bool,
                  out: Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = None,
-                 grad_beta: float = 0.0):
-    """dx, dA, dB, dbias.  `out` = (dA, dB, dbias) buffers to write/accumulate into (grad_beta)."""
+                 grad_beta: float = 0.0, *, phases: int = _lib.BWD_DATA | _lib.BWD_WEIGHTS,
+                 dx: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+    """dx, dA, dB, dbias.  `out` = (dA, dB, dbias) buffers to write/accumulate into (grad_beta).
+    `phases` selects the data-gradient and / or weight-gradient kernels (see include/sow_amd.h); a split
+    call must pass the same `workspace` (and `dx`) to both phases, each enqueued on the current stream."""
     lib = _lib.load()
     dev = _need_gpu(dy2, x2, h, A, B)
     dt = _dt(x2)
@@ -112,7 +119,8 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
     kind = acc_kind(acc_down, acc_up)
     r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
     dy2 = dy2.contiguous()
-    dx = torch.empty((T, d_in), dtype=x2.dtype, device=dev)
+    if dx is None:
+        dx = torch.empty((T, d_in), dtype=x2.dtype, device=dev)
     if out is None:
         dA = torch.empty((d_in, r), dtype=x2.dtype, device=dev)
         dB = torch.empty((r, d_out), dtype=x2.dtype, device=dev)
@@ -121,12 +129,14 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
     else:
         dA, dB, dbias = out
     nws = lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt)
-    ws = _ws(nws, dev)
-    _lib.check(lib.sow_backward(_ptr(dy2), _ptr(x2), _ptr(h), _ptr(A), _ptr(B),
-                                _ptr(acc_down) if kind != _lib.ACC_NONE else None,
-                                _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
-                                _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale),
-                                float(grad_beta), dt, _ptr(ws), ws.numel(), _stream()), "sow_backward")
+    ws = _ws(nws, dev) if workspace is None else workspace
+    if ws.numel() < nws:
+        raise ValueError("sow_amd: workspace too small")
+    _lib.check(lib.sow_backward_ex(_ptr(dy2), _ptr(x2), _ptr(h), _ptr(A), _ptr(B),
+                                   _ptr(acc_down) if kind != _lib.ACC_NONE else None,
+                                   _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
+                                   _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale),
+                                   float(grad_beta), dt, _ptr(ws), ws.numel(), int(phases), _stream()), "sow_backward")
     return dx, dA, dB, dbias
 
 
@@ -233,6 +243,29 @@ def tt_kron_core(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         raise ValueError("tt_kron_core: physical dimensions differ")
     out = torch.empty((ra0 * rb0, i, j, ra1 * rb1), dtype=torch.float32, device=dev)
     _lib.check(lib.sow_tt_kron_core(_ptr(a), _ptr(b), _ptr(out), ra0, rb0, i * j, ra1, rb1, _stream()), "sow_tt_kron_core")
+    return out
+
+
+def absmax(x: torch.Tensor) -> float:
+    """max |x| of an fp32 device tensor (one small kernel + a host read)."""
+    lib = _lib.load()
+    dev = _need_gpu(x)
+    x = x.contiguous().float()
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    _lib.check(lib.sow_absmax(_ptr(x), x.numel(), _ptr(out), _stream()), "sow_absmax")
+    return float(out.item())
+
+
+def small_inverse(mats: torch.Tensor) -> torch.Tensor:
+    """Inverse of a batch of [r, r] fp32 matrices (r <= 16)."""
+    lib = _lib.load()
+    dev = _need_gpu(mats)
+    m = mats.contiguous().float()
+    b, r, r2 = m.shape
+    if r != r2:
+        raise ValueError("small_inverse expects square matrices")
+    out = torch.empty_like(m)
+    _lib.check(lib.sow_small_inverse(_ptr(m), _ptr(out), b, r, _stream()), "sow_small_inverse")
     return out
 
 

@@ -143,6 +143,44 @@ def test_grad_accumulation_beta():
     assert rel_err(bufs[2].cpu(), 2 * db1.cpu()) < TOL
 
 
+def test_streaming_kernels_agree_with_generic_kernels(monkeypatch):
+    """A/B: the bf16 streaming chain kernel (chain2) against the generic chain kernel on the same inputs."""
+    from sow_amd import ops
+    T, di, do, r = 4608, 512, 1376, 50
+    x, dy, A, B, b, _, _ = _rand_case(T, di, do, r, None, True, 55)
+    g = lambda t: t.to(DEV, torch.bfloat16)
+    y2, h2 = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
+    dx2 = ops.sow_backward(g(dy), g(x), h2, g(A), g(B), None, None, 0.5, True)[0]
+    monkeypatch.setenv("SOW_AMD_FORCE_CHAIN_V1", "1")
+    y1, h1 = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
+    dx1 = ops.sow_backward(g(dy), g(x), h1, g(A), g(B), None, None, 0.5, True)[0]
+    monkeypatch.delenv("SOW_AMD_FORCE_CHAIN_V1")
+    assert rel_err(y2.float().cpu(), y1.float().cpu()) < 1e-2 and rel_err(dx2.float().cpu(), dx1.float().cpu()) < 1e-2
+    assert rel_err(h2.float().cpu().view(T, 64)[:, :50], h1.float().cpu().view(T, 64)[:, :50]) < 1e-2
+    assert torch.equal(h2.view(T, 64)[:, 63].float().cpu(), torch.ones(T)) and float(h2.view(T, 64)[:, 50:63].abs().max()) == 0.0
+
+
+def test_backward_phases_split_equals_fused():
+    """sow_backward_ex: DATA then WEIGHTS on the same workspace == the fused call (bit-exact)."""
+    from sow_amd import _lib, ops
+    for dtype, (T, di, do, r) in ((torch.bfloat16, (4200, 512, 264, 50)), (torch.float32, (300, 96, 160, 8))):
+        x, dy, A, B, b, _, _ = _rand_case(T, di, do, r, None, True, 99)
+        g = lambda t: t.to(DEV, dtype)
+        y, h = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
+        ref = ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, True)
+        ws = torch.empty(ops.workspace_bytes(T, di, do, r, 0, 0, dtype) + 256, dtype=torch.uint8, device=DEV)
+        dx = torch.empty(T, di, dtype=dtype, device=DEV)
+        outs = (torch.empty_like(ref[1]), torch.empty_like(ref[2]), torch.empty_like(ref[3]))
+        ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, True, out=outs, phases=_lib.BWD_DATA, dx=dx, workspace=ws)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, True, out=outs, phases=_lib.BWD_WEIGHTS, dx=dx, workspace=ws)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(dx, ref[0]) and torch.equal(outs[0], ref[1]) and torch.equal(outs[1], ref[2]) and torch.equal(outs[2], ref[3])
+
+
 def test_full_size_properties_bf16():
     """North-star size (T=32768, d=768, r=50, bf16): size-independent properties.
     y is linear in x; <dY, Y> = <dA, A> = <dB, B> (y is homogeneous of degree 1 in A and in B);
