@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
 # WRITE_SIZE, see profiles/); None until collected for the current kernel version.
-TRAFFIC_BYTES_PER_LAUNCH = 98.2e6  # profiles/r01_pmc_hbm_fetch_write.txt (bf16, chain2_kernel<false>)
+TRAFFIC_BYTES_PER_LAUNCH = 97.9e6  # profiles/r01_pmc_hbm_fetch_write_v3.txt (bf16, chain2_kernel<false>)
 LLAMA_60M = dict(hidden=512, inter=1376, layers=8)
 
 
@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--acc", default="none", choices=["none", "dense"], help="accumulator state of the layers")
+    ap.add_argument("--mode", default="stack", choices=["stack", "train"],
+                    help="stack: the 56-layer SoWLinear hot path (headline); train: a full llama_60m training step "
+                         "through the module-swap surface (prepare_sow, autograd, AdamW, accumulate), secondary figure")
+    ap.add_argument("--accumulate-every", type=int, default=4, help="--mode train: SoW accumulation period in steps")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: weight-gradient kernels on a side stream (measured: no gain, the kernels are HBM-bound)")
     return ap.parse_args()
@@ -166,6 +170,77 @@ def cpu_baseline(shapes, T, r):
                 sample=f"1 fwd+bwd pass over the 56 llama_60m SoWLinear shapes, T={T}, fp32, torch-CPU oracle, {dt:.2f} s")
 
 
+def train_mode(args, world, rank, device):
+    """Caller protocol of the reference's scripts/simple_train.py:316-333, 389-405, 425-428, 502-506, 566-572,
+    596-650 with synthetic tokens: llama_60m from the JSON's numbers, prepare_sow(rank 50, normal_QR),
+    bf16 cast after the swap, AdamW with two groups, accumulate + reset_optimizer between backward and step."""
+    import transformers
+    from sow_amd import SoWConfig, SoWLinear, accumulate, prepare_sow, reset_optimizer
+    torch.manual_seed(42)
+    cfg = transformers.LlamaConfig(hidden_size=512, intermediate_size=1376, num_hidden_layers=8, num_attention_heads=8,
+                                   vocab_size=32000, max_position_embeddings=1024, rms_norm_eps=1e-6,
+                                   tie_word_embeddings=False)
+    model = transformers.AutoModelForCausalLM.from_config(cfg)
+    targets = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+    model = prepare_sow(model, SoWConfig(target_modules=targets, rank=args.rank, init_method="normal_QR", scale=1.0,
+                                         decompose=None, device=str(device)))
+    special, ids = [], set()
+    for _, m in model.named_modules():
+        if isinstance(m, SoWLinear):
+            for wgt in list(m.downscale_weights) + list(m.upscale_weights):
+                special.append(wgt)
+                ids.add(id(wgt))
+    model = model.to(device=device, dtype=torch.bfloat16)
+    trainable = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
+    opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0},
+                             {"params": special, "lr": 1e-3, "weight_decay": 0.0}])
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], output_device=device.index,
+                                                          broadcast_buffers=False)
+    batch, seq = 128, 256
+    gen = torch.Generator(device=device).manual_seed(42 + rank)
+    tokens = torch.randint(0, 32000, (batch, seq), generator=gen, device=device)
+    step_no = [0]
+
+    def step():
+        loss = model(input_ids=tokens, labels=tokens.clone()).loss
+        loss.backward()
+        step_no[0] += 1
+        if step_no[0] % args.accumulate_every == 0:      # simple_train.py:618-626 (GA = 1)
+            accumulate(model.module if world > 1 else model)
+            reset_optimizer(opt, group_id=1)
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms = elapsed / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "llama_60m --architecture sow rank=50 training tokens/s (full step, synthetic tokens)",
+            "value": batch * seq * world / (ms * 1e-3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "llama_60m (HF LlamaForCausalLM from config) + prepare_sow rank 50, batch 128 x seq 256, "
+                                   f"AdamW 2 groups, accumulate every {args.accumulate_every} steps",
+                       "parallelism": f"ddp{world}", "final_loss": float(loss.detach())}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +257,11 @@ def main():
 
     from sow_amd import _lib
     _lib.load()  # fail loudly when the HIP library is missing
+    if args.mode == "train":
+        train_mode(args, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     stack = Stack(shapes, T, args.rank, dtype, device, args.acc, args.streams)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
