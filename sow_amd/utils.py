@@ -45,3 +45,16 @@ def closest_factorization(n, d):
             if p < o:
                 factors[-1] += n
             return factors, p
+
+
+def svd_weight(weight: torch.Tensor, rank: int = None):
+    """utils.py:32-57.  Analysis helper only (the reference uses it in export_alignment, outside the hot
+    path): forwards to torch.linalg.svd with the same fp32 up-cast / truncation / cast-back."""
+    src = weight.dtype
+    w = weight if src == torch.float32 else weight.to(torch.float32)
+    u, s, v = torch.linalg.svd(w)
+    if rank:
+        u, s, v = u[:, :rank], s[:rank], v[:rank, :]
+    if src != torch.float32:
+        u, s, v = u.type(src), s.type(src), v.type(src)
+    return u, s, v

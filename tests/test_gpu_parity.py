@@ -270,6 +270,22 @@ def test_accumulate_trace_golden(name, monkeypatch):
             assert float(layer.upscale_weights[i].data.abs().max()) == 0.0
 
 
+def test_reset_parameters_normal_qr_matches_oracle(monkeypatch):
+    """a3: SoWLinear(init_method='normal_QR') -> A = Q[:, :r], B = R[:r, :] of the QR of the Gaussian draw."""
+    from sow_amd import SoWLinear
+    gen = torch.Generator().manual_seed(12)
+    draw = torch.randn(384, 200, generator=gen) * 0.02
+    monkeypatch.setattr(SoWLinear, "_fresh_gaussian", lambda self, shape, device, dtype: draw.to(device, dtype))
+    for dtype in (torch.float32, torch.bfloat16):
+        layer = SoWLinear(384, 200, bias=True, rank=16, init_method="normal_QR", device=DEV, dtype=dtype)
+        a_ref, b_ref = O.sow_init_normal_qr(draw, 16, dtype)
+        tol = QR_TOL if dtype == torch.float32 else 1e-2
+        assert layer.downscale_weights[0].dtype == dtype and layer.upscale_weights[0].shape == (16, 200)
+        assert rel_err(layer.downscale_weights[0].data.float().cpu(), a_ref.float()) < tol
+        assert rel_err(layer.upscale_weights[0].data.float().cpu(), b_ref.float()) < tol
+        assert float(layer.bias.data.abs().max()) == 0.0
+
+
 def test_qr_golden():
     from sow_amd import ops
     g = load_golden("qr_svd")
