@@ -52,7 +52,7 @@ size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_l
 
 // workspace carve (identical in the query and in the calls)
 struct WsPlan {
-  size_t off_dh, off_t, off_p0, off_p1, total;
+  size_t off_dh, off_t, off_apad, off_p0, off_p1, total;
   int ns, slab_len;
 };
 static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
@@ -63,6 +63,8 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   off += al256((size_t)T * (size_t)(r_live <= 64 ? 64 : r_live) * es);
   w.off_t = off;
   if (acc_kind == SOW_ACC_LOWRANK && r_acc > 64) off += al256((size_t)T * r_acc * es);
+  w.off_apad = off;   // A zero-padded to [d_in, 64]: the k-contiguous K-extension operand of the dense backward
+  if (acc_kind == SOW_ACC_DENSE && r_live <= 64) off += al256((size_t)d_in * 64 * es);
   if (r_live <= 64) {
     const int cg = (d_in + 63) / 64 + (d_out + 63) / 64;
     w.ns = tn_pick_slabs(T, cg, dtype, &w.slab_len);
@@ -101,6 +103,21 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
   float beta = 0.f;
   int rc;
   if (acc_kind == SOW_ACC_DENSE) {
+    if (r_live <= 64 && h_save) {
+      // one product with the low-rank term as a K-extension:  y = [x, h] . [W_acc; B] + bias,  h = scale * x . A
+      ChainParams ph{};
+      ph.X = x, ph.Y = nullptr, ph.Hsave = h_save, ph.bias = nullptr;
+      ph.M = T, ph.ldx = d_in, ph.ldy = d_out, ph.D1 = d_in, ph.D2 = 0;
+      ph.F1b = A, ph.ldf1b = r_live, ph.F2b = B, ph.ldf2b = d_out, ph.rb = r_live;
+      ph.scale = scale, ph.beta = 0.f, ph.save_scaled = 0;
+      if (chain2_supported(ph, dtype) &&
+          gemm2_supported(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, y, d_out, bias, T, d_out, d_in, dtype)) {
+        rc = launch_chain2(ph, false, stream);
+        if (rc) return rc;
+        return launch_gemm2(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, r_live, y, d_out, bias, T, d_out, d_in,
+                            1.f, 0.f, stream);
+      }
+    }
     rc = launch_gemm(x, d_in, false, acc_down, d_out, false, y, d_out, nullptr, T, d_out, d_in, 1.f, 0.f, dtype, stream);
     if (rc) return rc;
     beta = 1.f;
@@ -169,11 +186,32 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
   void* dh = ws + w.off_dh;
   float beta = 0.f;
   int rc;
+  bool data_done = false;
   if (!do_data) {
     // weights-only call: dh was produced by an earlier SOW_BWD_DATA call on the same workspace
   } else if (acc_kind == SOW_ACC_DENSE) {
+    if (r_live <= 64) {
+      // one product with the low-rank term as a K-extension:  dX = [dY, dh] . [W_acc^T; A^T],  dh = scale * dY . B^T
+      ChainParams pd{};
+      pd.X = dy, pd.Y = nullptr, pd.Hsave = dh, pd.bias = nullptr;
+      pd.M = T, pd.ldx = d_out, pd.ldy = d_in, pd.D1 = d_out, pd.D2 = 0;
+      pd.F1b = B, pd.ldf1b = d_out, pd.F2b = A, pd.ldf2b = r_live, pd.rb = r_live;
+      pd.scale = scale, pd.beta = 0.f, pd.save_scaled = 1;
+      void* apad = ws + w.off_apad;
+      if (chain2_supported(pd, dtype) &&
+          gemm2_supported(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, dx, d_in, nullptr, T, d_in, d_out, dtype)) {
+        rc = launch_chain2(pd, true, stream);
+        if (rc) return rc;
+        rc = launch_pad64(A, apad, d_in, r_live, stream);
+        if (rc) return rc;
+        rc = launch_gemm2(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, 64, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f,
+                          stream);
+        if (rc) return rc;
+        data_done = true;
+      }
+    }
     // dX = dY . W_acc^T   (W_acc stored [d_in, d_out] = [N, K])
-    rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
+    if (!data_done) rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
     if (rc) return rc;
     beta = 1.f;
   } else if (acc_kind == SOW_ACC_LOWRANK) {
@@ -202,7 +240,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
     p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
     p.scale = scale, p.beta = beta, p.save_scaled = 1;
-    if (do_data) {
+    if (do_data && !data_done) {
       rc = launch_chain(p, dtype, true, stream);
       if (rc) return rc;
     }
@@ -270,6 +308,10 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
 
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
              const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream) {
+  // tall bf16 products with a row-major left operand: the LDS-DMA streaming kernel
+  if (!trans_a && gemm2_supported(A, lda, B, ldb, trans_b != 0, nullptr, 0, nullptr, 0, C, ldc, bias, M, N, K, dtype))
+    return launch_gemm2(A, lda, B, ldb, trans_b != 0, nullptr, 0, nullptr, 0, 0, C, ldc, bias, M, N, K, alpha, beta,
+                        (hipStream_t)stream);
   return launch_gemm(A, lda, trans_a != 0, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
 }
 

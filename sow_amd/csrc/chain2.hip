@@ -35,6 +35,7 @@
 //   c ^ (((row >> 1) & 1) << 2)    for transposed-read consumers (forward factors)
 // DMA writes LDS lane-linearly, so the XOR is applied to the per-lane SOURCE address.
 #include "kernels.hpp"
+#include "lds_dma.hpp"
 
 namespace sow {
 
@@ -55,46 +56,6 @@ constexpr int C2_THREADS = 64 * (C2_NCW + C2_NLW);
 
 __device__ __attribute__((aligned(256))) uint32_t g_zero_page2[64];
 
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-#define DS_READ_B128(dst, addr, off) \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define DS_READ_B64(dst, addr, off) \
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define DS_READ_B32(dst, addr, off) \
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define DS_READ_TR(dst, addr, off) \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define LGKM_WAIT0()                                  \
-  do {                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);                \
-  } while (0)
-
-__device__ __forceinline__ void raw_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-// wait until all but the `newer` most recent groups of PER instructions have completed
-template <int PER> __device__ __forceinline__ void wait_groups(int newer) {
-  switch (newer) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PER) : "memory"); break;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0], lo[1], hi[0], hi[1]}; }
 template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
   return TR ? (c ^ (((row >> 1) & 1) << 2)) : (c ^ ((row >> 1) & 7));
 }
@@ -125,7 +86,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
     // the last row of A, kept in a register for the fix-up by the loader wave that DMAs that row
     // (rows 32*lw .. 32*lw+31 of a chunk belong to loader wave lw, so its own counted wait orders the
     // fix-up after its DMA)
-    const bool own_last = lw == ((rows_a - 1) & 63) / (8 * C2_LPW);
+    const bool own_last = rows_a > 0 && lw == ((rows_a - 1) & 63) / (8 * C2_LPW);
     uint32_t last_row_dw = 0u;
     if (own_last && lane < 32 && 2 * lane < rb) last_row_dw = *((const uint32_t*)(Amat + (int64_t)(rows_a - 1) * rb) + lane);
     asm volatile("" : "+v"(last_row_dw));  // consume now: the compiler's wait for this load lands here, not mid-pipeline
@@ -189,7 +150,12 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
       raw_barrier();   // chunk c visible to the consumers; they have finished chunk c-1
       if (c + C2_AHEAD < total) issue(c + C2_AHEAD);   // slot held chunk c-2: free
     }
-    if (nsl > 0) raw_barrier();   // matches the compute waves' final "last slice parked" barrier
+    if (nsl > 0) {
+      raw_barrier();   // matches the compute waves' final "last slice parked" barrier
+    } else {           // H-only call (D2 == 0): the hand-off barriers were not met inside the loop
+      raw_barrier();
+      raw_barrier();
+    }
     return;
   }
 

@@ -62,6 +62,14 @@ int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);
 // gemm.hip
 int launch_gemm(const void* A, int64_t lda, bool transA, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
                 const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream);
+// gemm2.hip (bf16 streaming GEMM with K-extension: the dense-accumulator form of the layer)
+bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                     const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                     int dtype);
+int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                 const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                 float alpha, float beta, hipStream_t stream);
+int launch_pad64(const void* in, void* out, int rows, int r, hipStream_t stream);
 // qr.hip
 int launch_cast_copy(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
                      int cols, hipStream_t stream);

@@ -1,0 +1,52 @@
+// LDS-DMA / inline-asm LDS read helpers shared by the streaming kernels (chain2.hip, gemm2.hip).
+//
+// Why inline asm: while an LDS-DMA (`global_load_lds_dwordx4`) is outstanding hipcc guards every
+// compiler-visible LDS read with `s_waitcnt vmcnt(0)`, which would drain the rings at every step.
+// Reads issued through these macros are invisible to that logic; the kernels order them by hand with
+// counted `s_waitcnt vmcnt(N)`, raw `s_barrier` and `s_waitcnt lgkmcnt(0)`.
+#pragma once
+#include "common.hpp"
+
+namespace sow {
+
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+#define DS_READ_B128(dst, addr, off) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define DS_READ_B64(dst, addr, off) \
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define DS_READ_B32(dst, addr, off) \
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define DS_READ_TR(dst, addr, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define LGKM_WAIT0()                                  \
+  do {                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+
+__device__ __forceinline__ void raw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+// wait until all but the `newer` most recent groups of PER instructions have completed
+template <int PER> __device__ __forceinline__ void wait_groups(int newer) {
+  switch (newer) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PER) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * PER) : "memory"); break;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0], lo[1], hi[0], hi[1]}; }
+}  // namespace sow
