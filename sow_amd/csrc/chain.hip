@@ -420,6 +420,10 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream) {
     const int rc = launch_chain2(p, bwd, stream);
     if (rc != SOW_ERR_ALIGN) return rc;  // factor alignment not met: fall through to the generic kernel
   }
+  if (chain2f_supported(p, dtype) && !getenv("SOW_AMD_FORCE_CHAIN_V1")) {
+    const int rc = launch_chain2f(p, bwd, stream);
+    if (rc != SOW_ERR_ALIGN) return rc;
+  }
   const int ve = dtype == SOW_F32 ? 4 : 8;
   const bool vec = p.D1 % ve == 0 && p.D2 % ve == 0 && p.ldx % ve == 0 && p.ldy % ve == 0 && aligned16(p.X) &&
                    aligned16(p.Y) && (!p.bias || aligned16(p.bias));

@@ -20,6 +20,9 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
 bool chain2_supported(const ChainParams& p, int dtype);
 int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream);
+// chain2f.hip (fp32 streaming version)
+bool chain2f_supported(const ChainParams& p, int dtype);
+int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream);
 // skinny_tn.hip
 struct TnJob {
   const void* M;
