@@ -12,6 +12,7 @@
 // Column groups of one slab are NS blocks apart (NS % 8 == 0) so they share an XCD and S is served
 // from that XCD's L2 after the first read.
 #include "kernels.hpp"
+#include "lds_dma.hpp"
 
 namespace sow {
 
@@ -352,6 +353,136 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_kernel(const TnParams p
   }
 }
 
+// =================================================================================================
+// fp32 fast path: the same wave-private LDS-DMA rings with exact-fp32 MFMA (32x32x2).
+//
+// fp32 needs no transposed reads: the MFMA takes ONE token per lane-half, and with the tiles in their
+// natural [token][column] layout lane li reads its column of token 2kp + lh with a plain row-wise read.
+// To fetch both 32-row tiles of an operand in one instruction, lane li owns columns (2 li, 2 li + 1):
+// tile a of the M operand is "columns == a (mod 2)", so one ds_read_b64 along the row (32 lanes = 256
+// contiguous bytes, conflict-free) feeds two MFMAs, and accumulator (a, c) register `reg` of lane
+// (li, lh) is G[2 * acc_row + a][2 * li + c].  Groups are 8 tokens (4 KiB: 2 + 2 DMA instructions), 4 in
+// flight per wave, 64 KiB of LDS, two workgroups per CU.  Per group: 8 ds_read_b64, 16 MFMAs (1024
+// cycles): the kernel is MFMA-bound at ~the HBM rate (AI = 32 flop/B).
+// =================================================================================================
+constexpr int TNF_DEPTH = 4;
+constexpr int TNF_STAGE_BYTES = 4096;       // [8][64] fp32 M tile + [8][64] fp32 S tile
+
+__global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int b = blockIdx.x, jid = 0;
+  if (p.njobs > 1 && b >= p.job[0].ncg * p.ns) {
+    b -= p.job[0].ncg * p.ns;
+    jid = 1;
+  }
+  const float* Mg = (const float*)(jid ? p.job[1].M : p.job[0].M);
+  const float* Sg = (const float*)(jid ? p.job[1].S : p.job[0].S);
+  float* Pg = jid ? p.job[1].partial : p.job[0].partial;
+  const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
+  const int D = jid ? p.job[1].D : p.job[0].D;
+  const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
+  const int cg = b / p.ns, slab = b % p.ns;
+  const int d0 = cg * TN_BD;
+  const int64_t t_begin = (int64_t)slab * p.slab_len;
+  int64_t t_end = t_begin + p.slab_len;
+  if (t_end > p.T) t_end = p.T;
+  char* ring = smem + w * (TNF_DEPTH * TNF_STAGE_BYTES);
+
+  const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 7) / 8) : 0;
+  const int nw = ngroups > w ? (ngroups - w + 3) / 4 : 0;  // groups of this wave (group g -> wave g % 4)
+
+  const int drow = lane >> 4, dpc = lane & 15;   // DMA lane -> (row in a 4-row block, 16-byte chunk)
+  auto issue = [&](int i) {
+    const int64_t tt0 = t_begin + (int64_t)(w + 4 * i) * 8;
+    char* slot = ring + (i % TNF_DEPTH) * TNF_STAGE_BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int64_t tt = tt0 + half * 4 + drow;
+      const int dcol = d0 + dpc * 4;
+      const void* zp = (const void*)(g_zero_page + (lane & 7) * 4);
+      const void* srcM = (tt < t_end && dcol < D) ? (const void*)(Mg + tt * ldm + dcol) : zp;
+      const void* srcS = (tt < t_end) ? (const void*)(Sg + tt * 64 + dpc * 4) : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcM,
+                                       (__attribute__((address_space(3))) void*)(slot + half * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcS,
+                                       (__attribute__((address_space(3))) void*)(slot + 2048 + half * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  const uint32_t lane_off = (uint32_t)(lh * 256 + li * 8);   // token row lh of a pair, columns 2 li, 2 li + 1
+  const int pre = nw < TNF_DEPTH ? nw : TNF_DEPTH;
+  for (int i = 0; i < pre; ++i) issue(i);
+  for (int i = 0; i < nw; ++i) {
+    const int newer = (nw - 1 - i) < (TNF_DEPTH - 1) ? (nw - 1 - i) : (TNF_DEPTH - 1);
+    tn_wait_stages(newer);
+    const uint32_t ad = ring_addr + (uint32_t)((i % TNF_DEPTH) * TNF_STAGE_BYTES) + lane_off;
+    // NB: float-typed vectors on purpose -- with uint32 vectors + bit_cast hipcc (ROCm 7.2) folds element 1
+    // of the pair into element 0 when the value feeds an MFMA intrinsic
+    f32x2 m0, m1, m2, m3, s0, s1, s2, s3;
+    DS_READ_B64(m0, ad, 0);
+    DS_READ_B64(s0, ad, 2048);
+    DS_READ_B64(m1, ad, 512);
+    DS_READ_B64(s1, ad, 2560);
+    DS_READ_B64(m2, ad, 1024);
+    DS_READ_B64(s2, ad, 3072);
+    DS_READ_B64(m3, ad, 1536);
+    DS_READ_B64(s3, ad, 3584);
+    LGKM_WAIT0();
+#define TNF_PAIR(MV, SV)                                                                       \
+  {                                                                                            \
+    const float ma0 = MV[0], ma1 = MV[1];                                                      \
+    const float sc0 = SV[0], sc1 = SV[1];                                                      \
+    acc[0][0] = mfma32(ma0, sc0, acc[0][0]);                                                   \
+    acc[0][1] = mfma32(ma0, sc1, acc[0][1]);                                                   \
+    acc[1][0] = mfma32(ma1, sc0, acc[1][0]);                                                   \
+    acc[1][1] = mfma32(ma1, sc1, acc[1][1]);                                                   \
+  }
+    TNF_PAIR(m0, s0)
+    TNF_PAIR(m1, s1)
+    TNF_PAIR(m2, s2)
+    TNF_PAIR(m3, s3)
+#undef TNF_PAIR
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + TNF_DEPTH < nw) issue(i + TNF_DEPTH);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // cross-wave sum through LDS (aliases the rings), un-interleaving rows and columns on the way
+  float* red = (float*)smem;  // [4 waves][64][64]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        red[w * 4096 + (2 * acc_row(reg, lane) + a) * 64 + 2 * li + c] = acc[a][c][reg];
+  __syncthreads();
+  float* P = Pg + ((int64_t)slab * ncg * TN_BD + d0) * 64;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = t + 256 * it;
+    f32x4 q0 = *(const f32x4*)(red + v * 4);
+    const f32x4 q1 = *(const f32x4*)(red + 4096 + v * 4);
+    const f32x4 q2 = *(const f32x4*)(red + 8192 + v * 4);
+    const f32x4 q3 = *(const f32x4*)(red + 12288 + v * 4);
+    q0 = (q0 + q1) + (q2 + q3);
+    *(f32x4*)(P + v * 4) = q0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic slab reduction + crop + optional transpose + cast.
 //   out[d][r]   (transpose = 0, ld = out_ld)   or   out[r][d]   (transpose = 1)
@@ -409,14 +540,27 @@ template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(co
 // ---------------------------------------------------------------------------------------------
 int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len) {
   const int bt = dtype == SOW_F32 ? TnCfg<float>::BT : TnCfg<bf16_t>::BT;
-  // aim for ~2 workgroups per CU (512) but keep slabs >= 512 tokens so the partial traffic
-  // (ns * D * 64 * 4 bytes) stays a small fraction of the streamed operand
-  int ns = (512 + total_colgroups - 1) / total_colgroups;
+  // Two workgroups per CU are resident (64 KiB of LDS each), 512 in all; slabs stay >= 512 tokens so the
+  // partial traffic (ns * D * 64 * 4 bytes) is a small fraction of the streamed operand.
+  //   bf16 (HBM-bound): ~512 blocks rounded UP to a multiple of 8 slabs -- the column groups of one slab then
+  //     share an XCD and S is served from that L2; the small second round is hidden by the memory system
+  //     (measured: 576 blocks 25.9 us vs 504 blocks 28.1 us at d = 768).
+  //   fp32 (MFMA-bound): AT MOST 512 blocks -- a 13 % overshoot is a second, nearly empty round on a saturated
+  //     matrix pipe (measured: 576 blocks 93 us vs 504 blocks 74 us).
+  int ns;
   int64_t max_ns = (T + 511) / 512;
   if (max_ns < 1) max_ns = 1;
-  if (ns > max_ns) ns = (int)max_ns;
-  if (ns < 1) ns = 1;
-  if (ns > 8) ns = (ns + 7) & ~7;  // multiple of 8: same-slab blocks share an XCD
+  if (dtype == SOW_F32) {
+    ns = 512 / total_colgroups;
+    if (ns > max_ns) ns = (int)max_ns;
+    if (ns < 1) ns = 1;
+    if (ns > 8 && (ns & ~7) * 10 >= ns * 9) ns &= ~7;
+  } else {
+    ns = (512 + total_colgroups - 1) / total_colgroups;
+    if (ns > max_ns) ns = (int)max_ns;
+    if (ns < 1) ns = 1;
+    if (ns > 8) ns = (ns + 7) & ~7;
+  }
   int64_t len = (T + ns - 1) / ns;
   len = (len + bt - 1) / bt * bt;
   if (len < bt) len = bt;
@@ -450,9 +594,25 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
     } else {
       hipLaunchKernelGGL(tn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
     }
-  } else if (dtype == SOW_F32)
-    hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
-  else
+  } else if (dtype == SOW_F32) {
+    bool dma = p.slab_len % 8 == 0;
+    for (int j = 0; j < p.njobs; ++j) {
+      const TnJob& J = p.job[j];
+      dma = dma && J.D % 4 == 0 && J.ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
+    }
+    if (dma) {
+      constexpr int LDS = 4 * TNF_DEPTH * TNF_STAGE_BYTES;  // 64 KiB
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tn_partial_dma_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(tn_partial_dma_f32_kernel, dim3(blocks), dim3(256), LDS, stream, p);
+    } else {
+      hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
+    }
+  } else
     return SOW_ERR_DTYPE;
   SOW_CHECK_LAUNCH();
   return SOW_OK;
