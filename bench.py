@@ -246,10 +246,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; ranks beyond the visible devices (a rehearsal of the N > 1 path on a 1-GPU box) share them
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        backend = os.environ.get("SOW_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (xGMI); "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     es = 2 if args.dtype == "bf16" else 4
     shapes = layer_shapes()
@@ -324,7 +330,7 @@ def main():
         # dominant kernel (largest total time in profiles/r01_bench_v2_kernel_stats.csv): the forward chain
         # kernel.  Algorithmic bytes per launch = T*(d_in + d_out + r)*s averaged over the 56 layers
         # (x read once, y written once, h saved once).
-        kname = "sow::chain2_kernel<false> (fused forward chain)" if args.dtype == "bf16" else "sow::chain_kernel<float, fwd>"
+        kname = "sow::chain2_kernel<false> (fused forward chain)" if args.dtype == "bf16" else "sow::chain2f_kernel<false> (fused forward chain, fp32)"
         kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / n_layers
         kms = fwd_ms / n_layers
         achieved = kbytes / (kms * 1e-3) / 1e9
