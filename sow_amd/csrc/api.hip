@@ -31,6 +31,14 @@ static inline bool ok_dtype(int d) { return d == SOW_F32 || d == SOW_BF16; }
 static inline bool al4p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
 static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// row-major A, plain product: the streaming kernel when it fills the chip, else the 128x128 kernel
+static int gemm_auto(const void* A, int64_t lda, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
+                     const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream) {
+  if (gemm2_supported(A, lda, B, ldb, transB, nullptr, 0, nullptr, 0, C, ldc, bias, M, N, K, dtype))
+    return launch_gemm2(A, lda, B, ldb, transB, nullptr, 0, nullptr, 0, 0, C, ldc, bias, M, N, K, alpha, beta, stream);
+  return launch_gemm(A, lda, false, B, ldb, transB, C, ldc, bias, M, N, K, alpha, beta, dtype, stream);
+}
+
 extern "C" {
 
 int sow_version(void) { return 100; }
@@ -118,7 +126,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
                             1.f, 0.f, stream);
       }
     }
-    rc = launch_gemm(x, d_in, false, acc_down, d_out, false, y, d_out, nullptr, T, d_out, d_in, 1.f, 0.f, dtype, stream);
+    rc = gemm_auto(x, d_in, acc_down, d_out, false, y, d_out, nullptr, T, d_out, d_in, 1.f, 0.f, dtype, stream);
     if (rc) return rc;
     beta = 1.f;
   } else if (acc_kind == SOW_ACC_LOWRANK) {
@@ -211,7 +219,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       }
     }
     // dX = dY . W_acc^T   (W_acc stored [d_in, d_out] = [N, K])
-    if (!data_done) rc = launch_gemm(dy, d_out, false, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
+    if (!data_done) rc = gemm_auto(dy, d_out, acc_down, d_out, true, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f, dtype, stream);
     if (rc) return rc;
     beta = 1.f;
   } else if (acc_kind == SOW_ACC_LOWRANK) {
@@ -308,10 +316,7 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
 
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
              const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream) {
-  // tall bf16 products with a row-major left operand: the LDS-DMA streaming kernel
-  if (!trans_a && gemm2_supported(A, lda, B, ldb, trans_b != 0, nullptr, 0, nullptr, 0, C, ldc, bias, M, N, K, dtype))
-    return launch_gemm2(A, lda, B, ldb, trans_b != 0, nullptr, 0, nullptr, 0, 0, C, ldc, bias, M, N, K, alpha, beta,
-                        (hipStream_t)stream);
+  if (!trans_a) return gemm_auto(A, lda, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
   return launch_gemm(A, lda, trans_a != 0, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
 }
 

@@ -391,11 +391,7 @@ template <typename T, bool BWD, bool VEC, bool FASTF> static int launch_chain_k(
   const int grid = ceil_div(p.M, CH_BM);
   if (grid <= 0) return SOW_OK;
   auto k = chain_kernel<T, BWD, VEC, FASTF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
-    attr_set = true;
-  }
+  SOW_SET_MAX_LDS_ONCE(L::BYTES, chain_kernel<T, BWD, VEC, FASTF>);
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), L::BYTES, stream, p);
   SOW_CHECK_LAUNCH();
   return SOW_OK;

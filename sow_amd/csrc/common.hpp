@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/sow_amd.h"
 
 namespace sow {
@@ -98,6 +100,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Raise a kernel's dynamic-LDS limit exactly once per process (thread-safe: forward runs on the caller's thread,
+// backward on the autograd thread).  The kernel expression goes last because template-ids contain commas.
+#define SOW_SET_MAX_LDS_ONCE(bytes, ...)                                                                            \
+  do {                                                                                                              \
+    static std::once_flag once__;                                                                                   \
+    std::call_once(once__, [] {                                                                                     \
+      (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));    \
+    });                                                                                                             \
+  } while (0)
 
 #define SOW_CHECK_LAUNCH()                     \
   do {                                         \

@@ -26,6 +26,7 @@
 #include "kernels.hpp"
 #include "epilogue.hpp"
 #include "lds_dma.hpp"
+#include <cstdlib>
 
 namespace sow {
 
@@ -240,7 +241,10 @@ bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
                      const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                      int dtype) {
   if (dtype != SOW_BF16 || !A || !B || !C) return false;
-  if (M < 2048 || N < 64 || K < 32) return false;          // short problems: the 128x128 kernel fills the chip better
+  // one 256x256 tile per CU: below ~160 tiles (256 CUs) the 128x128 kernel fills the chip better (measured at the
+  // finetune shapes of configs 4-5, tools/gemm_probe2.py: 172 tiles 143 us vs 206 us, 96 tiles 99 us vs 60 us)
+  if (N < 64 || K < 32 || (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160) return false;
+  if (getenv("SOW_AMD_FORCE_GEMM_V1")) return false;      // A/B switch, as SOW_AMD_FORCE_CHAIN_V1
   if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return false;
   if (!g2_al16(A) || !g2_al16(B) || !g2_al16(C) || (bias && !g2_al16(bias))) return false;
   if (A2) {
@@ -263,18 +267,10 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
   if (nt) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-      attr_set = true;
-    }
+    SOW_SET_MAX_LDS_ONCE(G2_LDS, gemm2_kernel<true>);
     hipLaunchKernelGGL(gemm2_kernel<true>, dim3((unsigned)tiles), dim3(G2_THREADS), G2_LDS, stream, p);
   } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-      attr_set = true;
-    }
+    SOW_SET_MAX_LDS_ONCE(G2_LDS, gemm2_kernel<false>);
     hipLaunchKernelGGL(gemm2_kernel<false>, dim3((unsigned)tiles), dim3(G2_THREADS), G2_LDS, stream, p);
   }
   SOW_CHECK_LAUNCH();

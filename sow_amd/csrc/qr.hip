@@ -189,11 +189,7 @@ int launch_qr_panel(const void* W, int64_t ldw, int in_dtype, int m, int kc, int
   else
     return SOW_ERR_DTYPE;
   SOW_CHECK_LAUNCH();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)qr_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
+  SOW_SET_MAX_LDS_ONCE(150 * 1024, qr_panel_kernel);
   hipLaunchKernelGGL(qr_panel_kernel, dim3(1), dim3(QR_THREADS), lds, stream, Pt, Qt, m, kc, r);
   SOW_CHECK_LAUNCH();
   return SOW_OK;

@@ -585,11 +585,7 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
     }
     if (dma) {
       constexpr int LDS = 4 * TN_DEPTH * TN_STAGE_BYTES;  // 64 KiB (rings; reused by the cross-wave sum)
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tn_partial_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-      }
+      SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_kernel);
       hipLaunchKernelGGL(tn_partial_dma_kernel, dim3(blocks), dim3(256), LDS, stream, p);
     } else {
       hipLaunchKernelGGL(tn_partial_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
@@ -603,11 +599,7 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
     }
     if (dma) {
       constexpr int LDS = 4 * TNF_DEPTH * TNF_STAGE_BYTES;  // 64 KiB
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tn_partial_dma_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-      }
+      SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_f32_kernel);
       hipLaunchKernelGGL(tn_partial_dma_f32_kernel, dim3(blocks), dim3(256), LDS, stream, p);
     } else {
       hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);

@@ -75,7 +75,8 @@ SHAPES = [
     (4100, 512, 1376, 50, None, True),        # ragged token tail, partial last factor chunk (1376 = 5.375 * 256)
     (4224, 1376, 512, 50, "dense", False),    # beta = 1 epilogue on top of the dense-accumulator GEMM
     (4096, 768, 768, 8, None, False),         # rank 8 (one MFMA k-step), north-star width
-    (4100, 512, 1376, 50, "dense", True),     # dense accumulator + bias: streaming GEMM with K-extension, ragged M and N tiles
+    (4100, 512, 1376, 50, "dense", True),     # dense accumulator + bias below the streaming GEMM's tile threshold: GEMM + chain (beta = 1)
+    (16500, 776, 1000, 50, "dense", True),    # dense accumulator + bias: streaming GEMM with K-extension (>= 160 tiles both ways), ragged M / N tiles, K tails of 8
     (5000, 264, 72, 50, "lowrank", True),     # widths that are not multiples of 64
 ]
 
@@ -342,11 +343,11 @@ def test_gemm(dtype, ta, tb):
 
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_streaming_bf16(tb):
-    """Tall bf16 products (M >= 2048) take the 256x256 LDS-DMA kernel: ragged M / N tiles, K tails of 8 and 32,
-    alpha / beta / bias epilogue."""
+    """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernel: ragged M / N tiles, K tails of 8
+    and 32, alpha / beta / bias epilogue."""
     from sow_amd import ops
     gen = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((2048, 256, 64), (4100, 1376, 1376), (2500, 520, 520), (3000, 72, 40)):
+    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40)):
         a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
         b = (torch.randn((N, K) if tb else (K, N), generator=gen) * 0.1).to(torch.bfloat16)
         c0 = torch.randn(M, N, generator=gen).to(torch.bfloat16)
