@@ -375,7 +375,8 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
 // =================================================================================================
 bool chain2f_supported(const ChainParams& p, int dtype) {
   auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (dtype != SOW_F32 || p.ra != 0 || p.rb <= 0 || p.rb > 64) return false;
+  // rb >= 2: with 4-byte rows (rb = 1) the zero-filled end-crossing pieces would cost the last three rows of A
+  if (dtype != SOW_F32 || p.ra != 0 || p.rb < 2 || p.rb > 64) return false;
   if (p.D1 % 4 || p.D2 % 4 || p.ldx % 4 || p.ldy % 4) return false;
   if (!a16(p.X) || !a16(p.Y) || (p.bias && !a16(p.bias)) || (p.Hsave && !a16(p.Hsave))) return false;
   if (p.M < 64) return false;   // (short inputs run T/64 workgroups either way; measured 1.4x faster than the generic kernel at T = 1024)
