@@ -86,3 +86,115 @@ def test_random_shape_vs_oracle(case):
     assert rel_err(dB.float().cpu(), dB_ref[0]) < tol_w
     if bias:
         assert rel_err(db.float().cpu(), db_ref) < tol_w
+
+
+# ------------------------------------------------------------------------------------------------ sow_gemm
+def _gemm_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        gran = rng.choice([1, 2, 4, 8, 8])
+        M = rng.choice([1, 7, 64, 129, 300, 1000, 2300]) if i % 4 else 8 * rng.randint(5200, 6000)   # every 4th: >= 160 tiles of 256 x 256
+        N = gran * rng.randint(1, max(1, 900 // gran)) if i % 4 else 8 * rng.randint(100, 170)
+        K = gran * rng.randint(1, max(1, 700 // gran)) if i % 4 else 8 * rng.randint(5, 90)
+        out.append((i, M, N, K, rng.random() < 0.5 and i % 4 != 0, rng.random() < 0.5, rng.choice([torch.float32, torch.bfloat16]),
+                    rng.choice([1.0, 0.5, -2.0]), rng.choice([0.0, 0.0, 1.0, 0.5]), rng.random() < 0.4))
+    return out
+
+
+GEMM_CASES = _gemm_cases(32, 4242)
+
+
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}x{c[3]}-{'T' if c[4] else 'N'}{'T' if c[5] else 'N'}-{str(c[6])[6:]}" for c in GEMM_CASES])
+def test_random_gemm(case):
+    """sow_gemm over every transpose combination, ragged and aligned extents, alpha / beta / bias, including shapes with
+    >= 160 output tiles that take the streaming kernel."""
+    from sow_amd import ops
+    i, M, N, K, ta, tb, dtype, alpha, beta, use_bias = case
+    gen = torch.Generator().manual_seed(500 + i)
+    a = torch.randn((K, M) if ta else (M, K), generator=gen).to(dtype)
+    b = (torch.randn((N, K) if tb else (K, N), generator=gen) * (1.0 / max(K, 1) ** 0.5)).to(dtype)
+    c0 = torch.randn(M, N, generator=gen).to(dtype)
+    bias = torch.randn(N, generator=gen).to(dtype) if use_bias else None
+    ref = alpha * ((a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())) + beta * c0.float()
+    if use_bias:
+        ref = ref + bias.float()
+    out = ops.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, out=c0.to(DEV).clone(), alpha=alpha, beta=beta,
+                   bias=None if bias is None else bias.to(DEV))
+    assert rel_err(out.float().cpu(), ref) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ sow_qr_thin
+def _qr_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        m = rng.choice([8, 50, 64, 100, 256, 512, 700, 1376])
+        ncols = rng.choice([8, 40, 64, 200, 512, 1376])
+        k = rng.randint(1, min(m, ncols, 160))
+        out.append((i, m, ncols, k, rng.choice([torch.float32, torch.bfloat16])))
+    return out
+
+
+QR_CASES = _qr_cases(16, 99)
+
+
+@pytest.mark.parametrize("case", QR_CASES, ids=[f"{c[0]}-{c[1]}x{c[2]}-k{c[3]}-{str(c[4])[6:]}" for c in QR_CASES])
+def test_random_qr_thin(case):
+    """Truncated Householder QR against torch.linalg.qr (same LAPACK sign convention) on well-conditioned Gaussians:
+    Q[:, :k], R[:k, :], orthonormality, and Q R = the rank-k part the reference's qr_weight returns (utils.py:8-30)."""
+    from sow_amd import ops
+    i, m, ncols, k, dtype = case
+    gen = torch.Generator().manual_seed(700 + i)
+    w = (torch.randn(m, ncols, generator=gen) * 0.02).to(dtype)
+    q, r = ops.qr_thin(w.to(DEV), k, need_r=True)
+    q_ref, r_ref = O.qr_weight(w, k)
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(q.float().cpu(), q_ref.float()) < tol
+    assert rel_err(r.float().cpu(), r_ref.float()) < tol
+    if dtype == torch.float32:
+        assert rel_err((q.t() @ q).cpu(), torch.eye(k)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ module level
+def _layer_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        out.append((i, rng.choice([(3, 17), (2, 5, 11), (64,), (4, 300)]), 8 * rng.randint(2, 40), 8 * rng.randint(2, 40),
+                    rng.choice([4, 8, 16]), rng.choice([1, 2, 3]), rng.random() < 0.5, rng.choice([torch.float32, torch.bfloat16])))
+    return out
+
+
+LAYER_CASES = _layer_cases(12, 31337)
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[f"{c[0]}-{'x'.join(map(str, c[1]))}-{c[2]}x{c[3]}-r{c[4]}-n{c[5]}-{str(c[7])[6:]}" for c in LAYER_CASES])
+def test_random_layer_autograd(case):
+    """SoWLinear through torch.autograd with n_iter factor pairs (concatenated for the C ABI), N-D inputs and bias:
+    outputs and every parameter gradient against the oracle."""
+    from sow_amd import SoWLinear
+    i, lead, d_in, d_out, r, n_iter, bias, dtype = case
+    torch.manual_seed(100 + i)
+    layer = SoWLinear(d_in, d_out, bias=bias, rank=r, n_iter=n_iter, scale=0.5, init_method="normal", device=DEV, dtype=dtype)
+    with torch.no_grad():
+        for p_ in list(layer.downscale_weights) + list(layer.upscale_weights):
+            p_.copy_((torch.randn(p_.shape) * 0.1).to(dtype))
+        if bias:
+            layer.bias.copy_((torch.randn(d_out) * 0.1).to(dtype))
+    x = torch.randn(*lead, d_in).to(dtype).to(DEV).requires_grad_(True)
+    dy = torch.randn(*lead, d_out).to(dtype).to(DEV)
+    y = layer(x)
+    y.backward(dy)
+    f = lambda t: t.detach().float().cpu()
+    As, Bs = [f(p_) for p_ in layer.downscale_weights], [f(p_) for p_ in layer.upscale_weights]
+    y_ref = O.sow_forward(f(x), As, Bs, None, None, 0.5, f(layer.bias) if bias else None)
+    dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(f(dy), f(x), As, Bs, None, None, 0.5, bias)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert y.shape == (*lead, d_out)
+    assert rel_err(f(y), y_ref) < tol and rel_err(f(x.grad), dx_ref) < tol
+    for j in range(n_iter):
+        assert rel_err(f(layer.downscale_weights[j].grad), dA_ref[j]) < 2 * tol
+        assert rel_err(f(layer.upscale_weights[j].grad), dB_ref[j]) < 2 * tol
+    if bias:
+        assert rel_err(f(layer.bias.grad), db_ref) < 2 * tol
