@@ -393,21 +393,37 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnPara
   const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 7) / 8) : 0;
   const int nw = ngroups > w ? (ngroups - w + 3) / 4 : 0;  // groups of this wave (group g -> wave g % 4)
 
+  // DMA sources: per-lane running pointers advanced by a per-lane constant in issue order (2 VALU per DMA) -- on
+  // this path every non-MFMA instruction is paid for in matrix-pipe time.  Only a group that
+  // crosses t_end takes the checked path.
   const int drow = lane >> 4, dpc = lane & 15;   // DMA lane -> (row in a 4-row block, 16-byte chunk)
-  auto issue = [&](int i) {
+  const char* zp = (const char*)(g_zero_page + (lane & 7) * 4);
+  const bool mcol_ok = d0 + dpc * 4 < D;
+  const int64_t m_step = mcol_ok ? (int64_t)32 * ldm * 4 : 0;   // 4 waves x 8 tokens per step of this wave
+  const int64_t s_step = (int64_t)32 * 64 * 4;
+  const char* pm[2];
+  const char* ps[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int64_t tt = t_begin + (int64_t)w * 8 + hf * 4 + drow;
+    pm[hf] = mcol_ok ? (const char*)(Mg + tt * ldm + d0 + dpc * 4) : zp;
+    ps[hf] = (const char*)(Sg + tt * 64 + dpc * 4);
+  }
+  auto issue = [&](int i) {   // groups are issued strictly in order: pm / ps point at group i
     const int64_t tt0 = t_begin + (int64_t)(w + 4 * i) * 8;
     char* slot = ring + (i % TNF_DEPTH) * TNF_STAGE_BYTES;
+    const bool whole = tt0 + 8 <= t_end;   // wave-uniform
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const int64_t tt = tt0 + half * 4 + drow;
-      const int dcol = d0 + dpc * 4;
-      const void* zp = (const void*)(g_zero_page + (lane & 7) * 4);
-      const void* srcM = (tt < t_end && dcol < D) ? (const void*)(Mg + tt * ldm + dcol) : zp;
-      const void* srcS = (tt < t_end) ? (const void*)(Sg + tt * 64 + dpc * 4) : zp;
+      const void* srcM = pm[half];
+      const void* srcS = ps[half];
+      if (!whole && tt0 + half * 4 + drow >= t_end) srcM = zp, srcS = zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcM,
                                        (__attribute__((address_space(3))) void*)(slot + half * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcS,
                                        (__attribute__((address_space(3))) void*)(slot + 2048 + half * 1024), 16, 0, 0);
+      pm[half] += m_step;
+      ps[half] += s_step;
     }
   };
 
