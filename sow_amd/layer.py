@@ -111,7 +111,8 @@ class SoWLinear(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _cat_factors(self):
         if self.n_iter == 1:
-            return self.downscale_weights[0], self.upscale_weights[0]
+            # direct dict access: ParameterList.__getitem__ costs ~5 us per lookup on the per-call path
+            return self.downscale_weights._parameters["0"], self.upscale_weights._parameters["0"]
         # sum_i A_i B_i = [A_1 .. A_n] [B_1; ..; B_n]; autograd splits the gradients back
         return torch.cat(list(self.downscale_weights), dim=1), torch.cat(list(self.upscale_weights), dim=0)
 

@@ -42,12 +42,32 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device: Optional[torch.device] = None) -> int:
+    """hipStream_t of the current torch stream.  torch.cuda.current_stream() builds a Stream object (~20 us of host
+    time per call, as much as everything else in a layer call); the raw getter is ~1 us."""
+    if _raw_stream is not None:
+        idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+_WS_BYTES: dict = {}
+
+
+def _workspace_bytes(lib, T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dt: int) -> int:
+    """sow_workspace_bytes, memoised per shape (a ctypes round trip per layer call otherwise)."""
+    key = (T, d_in, d_out, r, r_acc, kind, dt)
+    n = _WS_BYTES.get(key)
+    if n is None:
+        n = _WS_BYTES[key] = int(lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt))
+    return n
 
 
 def acc_kind(acc_down: Optional[torch.Tensor], acc_up: Optional[torch.Tensor]) -> int:
@@ -88,17 +108,17 @@ def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, ac
     acc_up = acc_up.contiguous() if kind == _lib.ACC_LOWRANK else None
     bias = bias.contiguous() if bias is not None else None
     y = torch.empty((T, d_out), dtype=x2.dtype, device=dev)
-    h = torch.empty(lib.sow_h_save_elems(T, r), dtype=x2.dtype, device=dev)
-    nws = lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt)
-    ws = _ws(nws, dev)
+    h = torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)   # == sow_h_save_elems(T, r)
+    # the forward touches its workspace only for a low-rank accumulator wider than 64 (include/sow_amd.h)
+    ws = _ws(_workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt), dev) if (kind == _lib.ACC_LOWRANK and r_acc > 64) else None
     _lib.check(lib.sow_forward(_ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y), _ptr(h),
-                               T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), ws.numel(), _stream()),
-               "sow_forward")
+                               T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), 0 if ws is None else ws.numel(),
+                               _stream(dev)), "sow_forward")
     return y, h
 
 
 def workspace_bytes(T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dtype: torch.dtype) -> int:
-    return _lib.load().sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, _DT[dtype])
+    return _workspace_bytes(_lib.load(), T, d_in, d_out, r, r_acc, kind, _DT[dtype])
 
 
 def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down,
@@ -128,7 +148,7 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
         grad_beta = 0.0
     else:
         dA, dB, dbias = out
-    nws = lib.sow_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt)
+    nws = _workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt)
     ws = _ws(nws, dev) if workspace is None else workspace
     if ws.numel() < nws:
         raise ValueError("sow_amd: workspace too small")
@@ -136,7 +156,7 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
                                    _ptr(acc_down) if kind != _lib.ACC_NONE else None,
                                    _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
                                    _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale),
-                                   float(grad_beta), dt, _ptr(ws), ws.numel(), int(phases), _stream()), "sow_backward")
+                                   float(grad_beta), dt, _ptr(ws), ws.numel(), int(phases), _stream(dev)), "sow_backward")
     return dx, dA, dB, dbias
 
 
