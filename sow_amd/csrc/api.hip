@@ -208,10 +208,15 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       void* apad = ws + w.off_apad;
       if (chain2_supported(pd, dtype) &&
           gemm2_supported(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, dx, d_in, nullptr, T, d_in, d_out, dtype)) {
+        // A zero-padded to 64 columns rides along in the dh launch when that grid is large enough
+        const bool pad_fused = (int64_t)ceil_div(T, 64) * 64 >= d_in;
+        if (pad_fused) pd.pad_src = A, pd.pad_dst = apad, pd.pad_rows = d_in, pd.pad_r = r_live;
         rc = launch_chain2(pd, true, stream);
         if (rc) return rc;
-        rc = launch_pad64(A, apad, d_in, r_live, stream);
-        if (rc) return rc;
+        if (!pad_fused) {
+          rc = launch_pad64(A, apad, d_in, r_live, stream);
+          if (rc) return rc;
+        }
         rc = launch_gemm2(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, 64, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f,
                           stream);
         if (rc) return rc;

@@ -160,6 +160,22 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
   }
 
   // -------------------------------------------------------------------- compute waves
+  if (p.pad_dst && (int)blockIdx.x * 64 < p.pad_rows) {
+    // side job (first ceil(rows / 64) workgroups): two 8-column groups per thread, plain guarded loads
+    const bf16_t* src = (const bf16_t*)p.pad_src;
+    bf16_t* dst = (bf16_t*)p.pad_dst;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = t + 256 * it, row = blockIdx.x * 64 + (idx >> 3), c0 = (idx & 7) * 8;
+      if (row < p.pad_rows) {
+        u32x4 v;
+        bf16_t* e = (bf16_t*)&v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (c0 + j < p.pad_r) ? src[(int64_t)row * p.pad_r + c0 + j] : (bf16_t)0.f;
+        *(u32x4*)(dst + (int64_t)row * 64 + c0) = v;
+      }
+    }
+  }
   const int tg = w & 1, hh = w >> 1;   // token group, half (K half in phase 1, column tile in phase 2)
   const int li = lane & 31, lh = lane >> 5;
   const int g = lane >> 4, jj = lane & 15, q = jj >> 2, pp = jj & 3;  // transposed-read geometry

@@ -15,6 +15,11 @@ struct ChainParams {
   float scale, beta;
   int save_scaled;
   int fast_factors;
+  // side job of the bf16 streaming kernel: out[rows, 64] = [in[rows, r] | 0] (the zero-padded A that the dense
+  // backward's K-extension DMAs row by row); workgroup b copies rows 64 b .. 64 b + 63.  nullptr = none.
+  const void* pad_src;
+  void* pad_dst;
+  int pad_rows, pad_r;
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
