@@ -128,11 +128,34 @@ def load_sow(model, checkpoint_path):
             obj.data.copy_(tensor.data)
 
 
+_ACC_STREAMS: dict = {}
+_ACC_WIDTH = 8
+
+
 def accumulate(model):
-    """prepare.py:219-222."""
-    for _, module in model.named_modules():
-        if isinstance(module, SoWLinear):
-            module.accumulate()
+    """prepare.py:219-222: accumulate() on every SoWLinear.
+
+    The layers are independent and each one's re-factorisation is a single-workgroup Householder panel (latency
+    bound, ~0.5 ms), so on the GPU they are spread round-robin over a few side streams that fork from and join the
+    current stream: 56 layers take ~7 QR latencies instead of 56.  Host order is unchanged, so the Gaussian
+    re-initialisation draws come out of the generator exactly as in the sequential loop."""
+    mods = [m for _, m in model.named_modules() if isinstance(m, SoWLinear)]
+    dev = mods[0].downscale_weights[0].device if mods else None
+    if len(mods) < 2 or dev is None or dev.type != "cuda":
+        for m in mods:
+            m.accumulate()
+        return
+    cur = torch.cuda.current_stream(dev)
+    streams = _ACC_STREAMS.get(dev)
+    if streams is None:
+        streams = _ACC_STREAMS[dev] = [torch.cuda.Stream(device=dev) for _ in range(_ACC_WIDTH)]
+    for s in streams:
+        s.wait_stream(cur)
+    for i, m in enumerate(mods):
+        with torch.cuda.stream(streams[i % _ACC_WIDTH]):
+            m.accumulate()
+    for s in streams:
+        cur.wait_stream(s)
 
 
 def reset_optimizer(optimizer, group_id):
