@@ -53,6 +53,10 @@ const char* sow_error_string(int code);
 
 /* Bytes of workspace needed by sow_forward / sow_backward for this shape. */
 size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);
+/* Bytes of workspace sow_forward itself touches: 0 for most shapes (the caller may then pass NULL / 0), else the
+ * same figure as sow_workspace_bytes (a low-rank accumulator wider than 64; short bf16 inputs, whose chain is split
+ * over K and over the output columns to fill the chip). */
+size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);
 /* Elements (of dtype) the caller must allocate for h_save: T*64 when r_live <= 64, else T*r_live. */
 size_t sow_h_save_elems(int64_t T, int r_live);
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     "sow_version": (c_int, []),
     "sow_error_string": (c_char_p, [c_int]),
     "sow_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "sow_forward_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sow_h_save_elems": (c_size_t, [c_int64, c_int]),
     "sow_forward": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                                c_size_t, c_void_p]),

@@ -2,6 +2,7 @@
 // Host-side dispatch only: picks the fused low-rank chain / skinny-TN kernels for r <= 64 and composes
 // the dense GEMM kernel for everything else.  No allocation, no synchronisation, no global state.
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace sow {
 
@@ -30,6 +31,54 @@ static inline size_t esize(int dtype) { return dtype == SOW_F32 ? 4 : 2; }
 static inline bool ok_dtype(int d) { return d == SOW_F32 || d == SOW_BF16; }
 static inline bool al4p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
 static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- short inputs ---------------------------------------------------------------------------------
+// T / 64 workgroups cannot fill 256 CUs: below SHORT_NTB token blocks the bf16 streaming chain is launched as
+// phase 1 split over K (fp32 partials + h_reduce) and phase 2 split over the output columns (kernels.hpp).
+constexpr int SHORT_NTB = 128;
+static inline int short_want(int ntb) { return ntb > 0 ? (256 + ntb - 1) / ntb : 1; }
+static size_t short_hp_bytes(int64_t T, int d_in, int d_out, int r_live, int dtype) {
+  const int ntb = ceil_div(T, 64);
+  if (dtype != SOW_BF16 || r_live > 64 || ntb <= 0 || ntb > SHORT_NTB) return 0;
+  const int dmax = d_in > d_out ? d_in : d_out;
+  int ks = short_want(ntb);
+  const int nst = (dmax + 63) / 64;
+  if (ks > nst) ks = nst;
+  return al256((size_t)ks * (size_t)T * 64 * sizeof(float));
+}
+// the live-factor chain of one direction (Hsave required); returns SOW_ERR_UNSUPPORTED when the split does not apply
+static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* hpartial, hipStream_t stream) {
+  const int ntb = ceil_div(p.M, 64);
+  if (!hpartial || !p.Hsave || ntb > SHORT_NTB || !chain2_supported(p, dtype) || getenv("SOW_AMD_FORCE_CHAIN_V1") ||
+      getenv("SOW_AMD_NO_SHORT_SPLIT"))
+    return SOW_ERR_UNSUPPORTED;
+  const int want = short_want(ntb);
+  const int nst = (p.D1 + 63) / 64, nsl = (p.D2 + 63) / 64;
+  if (nst + nsl < 24) return SOW_ERR_UNSUPPORTED;   // tiny layers: three launches cost more than the idle CUs (26 vs 19 us at 64 x 256 x 256)
+  int rc;
+  // phase 1: H = scale * X . F1
+  int ks = want < nst ? want : nst;
+  if (ks > 1) {
+    ChainParams a = p;
+    a.ntb = ntb, a.st_per = ceil_div(nst, ks), a.sl_per = 0, a.Hpartial = hpartial, a.Hload = nullptr;
+    ks = ceil_div(nst, a.st_per);
+    rc = launch_chain2(a, bwd, stream);
+    if (rc) return rc == SOW_ERR_ALIGN ? SOW_ERR_UNSUPPORTED : rc;
+    rc = launch_h_reduce(hpartial, ks, p.Hsave, p.M, p.rb, p.scale, stream);
+    if (rc) return rc;
+  } else {
+    ChainParams a = p;
+    a.Y = nullptr, a.D2 = 0, a.bias = nullptr;   // H-only mode
+    rc = launch_chain2(a, bwd, stream);
+    if (rc) return rc == SOW_ERR_ALIGN ? SOW_ERR_UNSUPPORTED : rc;
+  }
+  if (nsl == 0) return SOW_OK;
+  // phase 2: Y = beta * Y + H . F2 + bias
+  ChainParams b = p;
+  const int kn = want < nsl ? want : nsl;
+  b.ntb = ntb, b.st_per = 0, b.sl_per = ceil_div(nsl, kn), b.Hpartial = nullptr, b.Hload = p.Hsave, b.Hsave = nullptr;
+  return launch_chain2(b, bwd, stream);
+}
 
 // row-major A, plain product: the streaming kernel when it fills the chip, else the 128x128 kernel
 static int gemm_auto(const void* A, int64_t lda, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
@@ -60,7 +109,7 @@ size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_l
 
 // workspace carve (identical in the query and in the calls)
 struct WsPlan {
-  size_t off_dh, off_t, off_apad, off_p0, off_p1, total;
+  size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, total;
   int ns, slab_len;
 };
 static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
@@ -73,6 +122,8 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   if (acc_kind == SOW_ACC_LOWRANK && r_acc > 64) off += al256((size_t)T * r_acc * es);
   w.off_apad = off;   // A zero-padded to [d_in, 64]: the k-contiguous K-extension operand of the dense backward
   if (acc_kind == SOW_ACC_DENSE && r_live <= 64) off += al256((size_t)d_in * 64 * es);
+  w.off_hp = off;     // fp32 partial H of the short-T split: splits * T * 64 floats, splits <= 256 / ceil(T / 64)
+  off += short_hp_bytes(T, d_in, d_out, r_live, dtype);
   if (r_live <= 64) {
     const int cg = (d_in + 63) / 64 + (d_out + 63) / 64;
     w.ns = tn_pick_slabs(T, cg, dtype, &w.slab_len);
@@ -83,6 +134,13 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   }
   w.total = off;
   return w;
+}
+
+size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
+  if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0 || !ok_dtype(dtype)) return 0;
+  const bool wide_acc = acc_kind == SOW_ACC_LOWRANK && r_acc > 64;
+  if (!wide_acc && short_hp_bytes(T, d_in, d_out, r_live, dtype) == 0) return 0;   // the forward does not touch it
+  return plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype).total + 256;
 }
 
 size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
@@ -155,6 +213,10 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
     p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
     p.F1b = A, p.ldf1b = r_live, p.F2b = B, p.ldf2b = d_out, p.rb = r_live;
     p.scale = scale, p.beta = beta, p.save_scaled = 0;
+    if (ws && workspace_bytes >= w.total) {
+      rc = launch_chain_short(p, dtype, false, (float*)(ws + w.off_hp), stream);
+      if (rc != SOW_ERR_UNSUPPORTED) return rc;
+    }
     return launch_chain(p, dtype, false, stream);
   }
   // generic rank: h = x A ; y = beta*y + scale * h B + bias
@@ -254,7 +316,8 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
     p.scale = scale, p.beta = beta, p.save_scaled = 1;
     if (do_data && !data_done) {
-      rc = launch_chain(p, dtype, true, stream);
+      rc = launch_chain_short(p, dtype, true, short_hp_bytes(T, d_in, d_out, r_live, dtype) ? (float*)(ws + w.off_hp) : nullptr, stream);
+      if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain(p, dtype, true, stream);
       if (rc) return rc;
     }
     if (!do_weights) return SOW_OK;

@@ -68,10 +68,17 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int64_t m0 = (int64_t)blockIdx.x * C2_BM;
+  // short-T split (kernels.hpp): workgroup = (token block, split); a split owns a range of phase-1 stages OR of
+  // phase-2 slices.  Without a split every workgroup owns all of both.
+  const int tb = p.ntb > 0 ? (int)blockIdx.x % p.ntb : (int)blockIdx.x;
+  const int split = p.ntb > 0 ? (int)blockIdx.x / p.ntb : 0;
+  const int64_t m0 = (int64_t)tb * C2_BM;
   const int D1 = p.D1, D2 = p.D2, rb = p.rb;
-  const int nst = (D1 + 63) / 64;   // phase-1 chunks = X stages
-  const int nsl = (D2 + 63) / 64;   // phase-2 chunks = output slices
+  const int nst_all = (D1 + 63) / 64, nsl_all = (D2 + 63) / 64;
+  const int st0 = p.st_per > 0 ? split * p.st_per : 0;   // first phase-1 stage of this workgroup
+  const int sl0 = p.sl_per > 0 ? split * p.sl_per : 0;   // first phase-2 slice
+  const int nst = p.sl_per > 0 ? 0 : (p.st_per > 0 ? (nst_all - st0 < p.st_per ? nst_all - st0 : p.st_per) : nst_all);
+  const int nsl = p.st_per > 0 ? 0 : (p.sl_per > 0 ? (nsl_all - sl0 < p.sl_per ? nsl_all - sl0 : p.sl_per) : nsl_all);
   const int total = nst + nsl;
   const bf16_t* Amat = (const bf16_t*)(BWD ? p.F2b : p.F1b);   // [rows_a, rb] contiguous
   const bf16_t* Bmat = (const bf16_t*)(BWD ? p.F1b : p.F2b);   // [rb, cols_b], ld = ldb
@@ -111,7 +118,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
     const int nb_chunks = (cols_b + 63) / 64;
     auto issue = [&](int c) {
       char* slot = smem + (c % C2_NSLOT) * C2_FSLOT;
-      const int ci = c < nst ? c : c - nst;   // chunk index inside its matrix
+      const int ci = c < nst ? st0 + c : sl0 + (c - nst);   // chunk index inside its matrix
       if (chunk_is_a(c)) {
 #pragma unroll
         for (int ii = 0; ii < C2_LPW; ++ii) {
@@ -136,7 +143,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
       wait_groups<C2_LPW>(newer);
       // fix-up: rewrite the last row of A (its DMA pieces past the end of the buffer were zero-filled)
       if (chunk_is_a(c)) {
-        const int base = (c < nst ? c : c - nst) * 64;
+        const int base = (c < nst ? st0 + c : sl0 + (c - nst)) * 64;
         const int lr = rows_a - 1 - base;
         if (own_last && lr >= 0 && lr < 64 && lane < 32) {
           const int cc = lane >> 2;
@@ -205,8 +212,8 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
     char* dst = ring + (st % C2_DEPTH) * C2_STAGE;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      const char* qq = xsrc[ii] + st * xstride[ii];
-      if (x_ragged && st == nst - 1 && st * 64 + xlc[ii] * 8 >= D1) qq = zp;
+      const char* qq = xsrc[ii] + (st0 + st) * xstride[ii];
+      if (x_ragged && (st0 + st) * 64 + xlc[ii] * 8 >= D1) qq = zp;
       dma16((const void*)qq, dst + (2 * hh + ii) * 1024);
     }
   };
@@ -294,6 +301,25 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
   // ================================================================== hand-off: sum the two K halves
   // barrier H0: every X read of the workgroup is done, so the rings can hold the exchange buffers
   // (fp32 [wave][tile][reg][lane], 8 KiB per wave); barrier H1: partials visible to the partner.
+  u32x4 hf[4];
+  const int64_t tok = tok0 + li;
+  if (p.Hload) {
+    // phase-2-only workgroup: H comes from memory.  hf[s] of lane (li, lh) = ranks 16s + 4lh + (0..3) and
+    // 16s + 8 + 4lh + (0..3) of token li; the 1.0 of column 63 (dbias trick) must not reach the product.
+    raw_barrier();
+    raw_barrier();
+    const bf16_t* Hl = (const bf16_t*)p.Hload + tok * 64 + 4 * lh;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      u32x2 lo = {0u, 0u}, hi = {0u, 0u};
+      if (tok < p.M) {
+        lo = *(const u32x2*)(Hl + 16 * s4);
+        hi = *(const u32x2*)(Hl + 16 * s4 + 8);
+      }
+      if (s4 == 3 && lh == 1 && rb < 64) hi[1] &= 0xffffu;
+      hf[s4] = join2(lo, hi);
+    }
+  } else {
   raw_barrier();
   {
     float* xch = (float*)(smem + C2_RING0) + w * 2048;
@@ -314,11 +340,21 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) hacc[rt][reg] += __builtin_bit_cast(float, pv[rt * 16 + reg]);
   }
+  if (p.Hpartial) {
+    // phase-1 slab of a short-T split: the raw fp32 sums of this K range, one 32-rank tile per half
+    if (tok < p.M) {
+      float* Hp = p.Hpartial + ((int64_t)split * p.M + tok) * 64 + hh * 32 + 4 * lh;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *(f32x4*)(Hp + 8 * rq) = hh ? (f32x4){hacc[1][4 * rq + 0], hacc[1][4 * rq + 1], hacc[1][4 * rq + 2], hacc[1][4 * rq + 3]}
+                                    : (f32x4){hacc[0][4 * rq + 0], hacc[0][4 * rq + 1], hacc[0][4 * rq + 2], hacc[0][4 * rq + 3]};
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) hf[s4] = (u32x4){0u, 0u, 0u, 0u};
+  } else {
   // scale, mask rank rows >= r (overlap garbage / zeros), round to bf16: hf[s] is the phase-2 B operand
   // of k-step s; the saved copy [M, 64] (scaled live columns, zeros, and 1.0 in column 63 when free --
   // the dbias trick of the skinny-TN kernel) is written as 8-byte row pieces, one 32-column tile per half.
-  const int64_t tok = tok0 + li;
-  u32x4 hf[4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     float hv[16];
@@ -341,7 +377,9 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
       }
     }
   }
+  }
 
+  }
   // ================================================================== phase 2: Y^T = F2^T . H^T (column tile hh)
   // Epilogue: Y^T has one token per lane, so a direct store would write 8-byte pieces of 32 different
   // rows (measured: 2x the time of full-row stores).  Each slice is transposed through a per-token-group
@@ -367,7 +405,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
     for (int pass = 0; pass < 2; ++pass) {
       const int r = 16 * hh + pass * 8 + (lane >> 3), c8 = lane & 7;
       const int64_t tk = tok0 + r;
-      const int col = sl_prev * 64 + c8 * 8;
+      const int col = (sl0 + sl_prev) * 64 + c8 * 8;
       if (tk < p.M && col < D2) {
         float v[8];
         const float* f0 = (const float*)&v0[pass];
@@ -448,6 +486,38 @@ bool chain2_supported(const ChainParams& p, int dtype) {
   return true;
 }
 
+// Hsave[t][c] = bf16(scale * sum_s Hpartial[s][t][c]) for c < rb, 0 above, 1.0 in column 63 when rb < 64
+__global__ __launch_bounds__(256) void h_reduce_kernel(const float* __restrict__ Hp, int nsplit, bf16_t* __restrict__ Hs, int64_t M,
+                                                       int rb, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 8-column group per thread
+  const int64_t tok = idx >> 3;
+  const int c0 = (int)(idx & 7) * 8;
+  if (tok >= M) return;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s) {
+    const f32x4 a = *(const f32x4*)(Hp + ((int64_t)s * M + tok) * 64 + c0);
+    const f32x4 b = *(const f32x4*)(Hp + ((int64_t)s * M + tok) * 64 + c0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += a[j], v[4 + j] += b[j];
+  }
+  u32x4 out;
+  bf16_t* e = (bf16_t*)&out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    e[j] = c < rb ? (bf16_t)(v[j] * scale) : ((c == 63 && rb < 64) ? (bf16_t)1.0f : (bf16_t)0.f);
+  }
+  *(u32x4*)(Hs + tok * 64 + c0) = out;
+}
+
+int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, hipStream_t stream) {
+  if (M <= 0) return SOW_OK;
+  hipLaunchKernelGGL(h_reduce_kernel, dim3((unsigned)((M * 8 + 255) / 256)), dim3(256), 0, stream, Hpartial, nsplit,
+                     (bf16_t*)Hsave, M, rb, scale);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
 int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream) {
   // B is DMA'd in aligned 16-byte pieces along its rows; A must be contiguous [rows, r] and 4-byte aligned
   const void* Bp = bwd ? p.F1b : p.F2b;
@@ -456,7 +526,11 @@ int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream) {
   const int64_t ldA = bwd ? p.ldf2b : p.ldf1b;
   if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 8 || (reinterpret_cast<uintptr_t>(Ap) & 3) || ldA != p.rb)
     return SOW_ERR_ALIGN;
-  const int grid = ceil_div(p.M, C2_BM);
+  int grid = ceil_div(p.M, C2_BM);
+  if (p.ntb > 0) {
+    const int nsplit = p.st_per > 0 ? ceil_div((p.D1 + 63) / 64, p.st_per) : ceil_div((p.D2 + 63) / 64, p.sl_per);
+    grid = p.ntb * nsplit;
+  }
   if (bwd) {
     SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<true>);
     hipLaunchKernelGGL(chain2_kernel<true>, dim3(grid), dim3(C2_THREADS), C2_LDS, stream, p);

@@ -59,6 +59,16 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 _WS_BYTES: dict = {}
+_FWD_WS_BYTES: dict = {}
+
+
+def _forward_workspace_bytes(lib, T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dt: int) -> int:
+    """sow_forward_workspace_bytes (0 for most shapes), memoised per shape."""
+    key = (T, d_in, d_out, r, r_acc, kind, dt)
+    n = _FWD_WS_BYTES.get(key)
+    if n is None:
+        n = _FWD_WS_BYTES[key] = int(lib.sow_forward_workspace_bytes(T, d_in, d_out, r, r_acc, kind, dt))
+    return n
 
 
 def _workspace_bytes(lib, T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dt: int) -> int:
@@ -109,8 +119,9 @@ def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, ac
     bias = bias.contiguous() if bias is not None else None
     y = torch.empty((T, d_out), dtype=x2.dtype, device=dev)
     h = torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)   # == sow_h_save_elems(T, r)
-    # the forward touches its workspace only for a low-rank accumulator wider than 64 (include/sow_amd.h)
-    ws = _ws(_workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt), dev) if (kind == _lib.ACC_LOWRANK and r_acc > 64) else None
+    # the forward touches a workspace only for some shapes (include/sow_amd.h: sow_forward_workspace_bytes)
+    nws = _forward_workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt)
+    ws = _ws(nws, dev) if nws else None
     _lib.check(lib.sow_forward(_ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y), _ptr(h),
                                T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), 0 if ws is None else ws.numel(),
                                _stream(dev)), "sow_forward")
