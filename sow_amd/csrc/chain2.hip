@@ -5,7 +5,7 @@
 // kernel:
 //   * LDS-DMA (`global_load_lds_dwordx4`) for EVERYTHING that is read: X streams through per-token-group
 //     rings of [32 tok x 64 k] stages (no VGPR staging, counted s_waitcnt vmcnt); two loader waves
-//     stream the factors as 64-row chunks into a 4-slot LDS ring, 2 chunks ahead of the consumers.
+//     stream the factors as 64-row chunks into a 4-slot LDS ring, 3 chunks ahead of the consumers.
 //   * `ds_read_b64_tr_b16`: the factors stay in their storage layout (A is [d_in, r], B is [r, d_out]);
 //     in the forward direction both have the contraction index as their ROW index and are read
 //     transposed; in the backward direction both are k-contiguous and read with ds_read_b128 / b64.
@@ -26,7 +26,7 @@
 // in phase 2 each takes one 32-column tile of every 64-column slice and half of the store rows.
 // Workgroup = 64 tokens = 6 waves: compute waves 0-3 (token group = w & 1, half = w >> 1) and loader
 // waves 4-5; 80 KiB of LDS, two workgroups per CU (12 waves, 3 per SIMD).  One raw s_barrier per
-// chunk hands chunk c to the consumers and frees slot (c-2) % 4 for the loaders.
+// chunk hands chunk c to the consumers and frees the slot of chunk c-1 for the loaders (chunk c+3).
 // All LDS reads of the compute waves are inline asm: for a compiler-visible LDS read hipcc emits
 // `s_waitcnt vmcnt(0)` while LDS-DMA is outstanding, which would drain the rings every step.
 //
@@ -46,7 +46,7 @@ constexpr int C2_BM = 32 * C2_NTG;    // tokens per workgroup
 constexpr int C2_DEPTH = 6;           // X stage slots per token group (5 in flight)
 constexpr int C2_STAGE = 4096;        // [32 tok][64 k] bf16
 constexpr int C2_NSLOT = 4;           // factor chunk slots
-constexpr int C2_AHEAD = 2;           // chunks the loaders run ahead (slot of chunk c+2 held chunk c-2)
+constexpr int C2_AHEAD = 3;           // chunks the loaders run ahead: the slot of chunk c+3 held chunk c-1, drained before barrier c (2 ahead: +2.7 % step time; 5 slots / 4 ahead with a 5-deep X ring: +1 %)
 constexpr int C2_FSLOT = 8192;        // [64][64] bf16
 constexpr int C2_LPW = 8 / C2_NLW;    // 1-KiB DMA instructions per loader wave per chunk
 constexpr int C2_RING0 = C2_NSLOT * C2_FSLOT;
@@ -155,7 +155,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
         raw_barrier();
       }
       raw_barrier();   // chunk c visible to the consumers; they have finished chunk c-1
-      if (c + C2_AHEAD < total) issue(c + C2_AHEAD);   // slot held chunk c-2: free
+      if (c + C2_AHEAD < total) issue(c + C2_AHEAD);   // its slot held chunk c-1: every consumer finished it before barrier c
     }
     if (nsl > 0) {
       raw_barrier();   // matches the compute waves' final "last slice parked" barrier
