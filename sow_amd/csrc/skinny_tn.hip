@@ -245,23 +245,40 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_kernel(const TnParams p
   const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 15) / 16) : 0;
   const int nw = ngroups > w ? (ngroups - w + 3) / 4 : 0;  // groups of this wave
 
-  // DMA lane geometry: lane -> (row in 8-row block, physical 16-byte chunk); logical chunk un-swizzled
+  // DMA lane geometry: lane -> (row in 8-row block, physical 16-byte chunk); logical chunk un-swizzled.
+  // Per-lane running source pointers, advanced by a per-lane constant in issue order (2 VALU per DMA); only a
+  // group that crosses t_end takes the checked path.
   const int drow = lane >> 3, dpc = lane & 7;
-  auto issue = [&](int i) {  // i-th group of this wave -> ring slot i % DEPTH
+  const char* zp = (const char*)(g_zero_page + (lane & 7) * 4);
+  const char* pm[2];
+  const char* ps[2];
+  int64_t m_step[2];
+  const int64_t s_step = (int64_t)64 * 64 * 2;   // 4 waves x 16 tokens per step of this wave
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = half * 8 + drow;
+    const int lc = dpc ^ (((row >> 1) & 1) << 2);
+    const int64_t tt = t_begin + (int64_t)w * 16 + row;
+    const bool ok = d0 + lc * 8 < D;
+    pm[half] = ok ? (const char*)(Mg + tt * ldm + d0 + lc * 8) : zp;
+    m_step[half] = ok ? (int64_t)64 * ldm * 2 : 0;
+    ps[half] = (const char*)(Sg + tt * 64 + lc * 8);
+  }
+  auto issue = [&](int i) {  // i-th group of this wave -> ring slot i % DEPTH (groups are issued in order)
     const int64_t tt0 = t_begin + (int64_t)(w + 4 * i) * 16;
     char* slot = ring + (i % TN_DEPTH) * TN_STAGE_BYTES;
+    const bool whole = tt0 + 16 <= t_end;   // wave-uniform
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      const int row = half * 8 + drow;
-      const int lc = dpc ^ (((row >> 1) & 1) << 2);
-      const int64_t tt = tt0 + row;
-      const int dcol = d0 + lc * 8;
-      const void* srcM = (tt < t_end && dcol < D) ? (const void*)(Mg + tt * ldm + dcol) : (const void*)(g_zero_page + (lane & 7) * 4);
-      const void* srcS = (tt < t_end) ? (const void*)(Sg + tt * 64 + lc * 8) : (const void*)(g_zero_page + (lane & 7) * 4);
+      const void* srcM = pm[half];
+      const void* srcS = ps[half];
+      if (!whole && tt0 + half * 8 + drow >= t_end) srcM = zp, srcS = zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcM,
                                        (__attribute__((address_space(3))) void*)(slot + half * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcS,
                                        (__attribute__((address_space(3))) void*)(slot + 2048 + half * 1024), 16, 0, 0);
+      pm[half] += m_step[half];
+      ps[half] += s_step;
     }
   };
 
