@@ -33,13 +33,13 @@ static inline bool al4p(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- short inputs ---------------------------------------------------------------------------------
-// T / 64 workgroups cannot fill 256 CUs: below SHORT_NTB token blocks the bf16 streaming chain is launched as
+// T / 64 workgroups cannot fill 256 CUs: below SHORT_NTB token blocks the streaming chain is launched as
 // phase 1 split over K (fp32 partials + h_reduce) and phase 2 split over the output columns (kernels.hpp).
 constexpr int SHORT_NTB = 128;
 static inline int short_want(int ntb) { return ntb > 0 ? (256 + ntb - 1) / ntb : 1; }
 static size_t short_hp_bytes(int64_t T, int d_in, int d_out, int r_live, int dtype) {
   const int ntb = ceil_div(T, 64);
-  if (dtype != SOW_BF16 || r_live > 64 || ntb <= 0 || ntb > SHORT_NTB) return 0;
+  if (r_live > 64 || ntb <= 0 || ntb > SHORT_NTB) return 0;
   const int dmax = d_in > d_out ? d_in : d_out;
   int ks = short_want(ntb);
   const int nst = (dmax + 63) / 64;
@@ -49,7 +49,9 @@ static size_t short_hp_bytes(int64_t T, int d_in, int d_out, int r_live, int dty
 // the live-factor chain of one direction (Hsave required); returns SOW_ERR_UNSUPPORTED when the split does not apply
 static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* hpartial, hipStream_t stream) {
   const int ntb = ceil_div(p.M, 64);
-  if (!hpartial || !p.Hsave || ntb > SHORT_NTB || !chain2_supported(p, dtype) || getenv("SOW_AMD_FORCE_CHAIN_V1") ||
+  const bool f32 = dtype == SOW_F32;
+  if (!hpartial || !p.Hsave || ntb > SHORT_NTB || !(f32 ? chain2f_supported(p, dtype) : chain2_supported(p, dtype)) ||
+      getenv("SOW_AMD_FORCE_CHAIN_V1") ||
       getenv("SOW_AMD_NO_SHORT_SPLIT"))
     return SOW_ERR_UNSUPPORTED;
   const int want = short_want(ntb);
@@ -62,14 +64,14 @@ static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* 
     ChainParams a = p;
     a.ntb = ntb, a.st_per = ceil_div(nst, ks), a.sl_per = 0, a.Hpartial = hpartial, a.Hload = nullptr;
     ks = ceil_div(nst, a.st_per);
-    rc = launch_chain2(a, bwd, stream);
+    rc = f32 ? launch_chain2f(a, bwd, stream) : launch_chain2(a, bwd, stream);
     if (rc) return rc == SOW_ERR_ALIGN ? SOW_ERR_UNSUPPORTED : rc;
-    rc = launch_h_reduce(hpartial, ks, p.Hsave, p.M, p.rb, p.scale, stream);
+    rc = launch_h_reduce(hpartial, ks, p.Hsave, p.M, p.rb, p.scale, dtype, stream);
     if (rc) return rc;
   } else {
     ChainParams a = p;
     a.Y = nullptr, a.D2 = 0, a.bias = nullptr;   // H-only mode
-    rc = launch_chain2(a, bwd, stream);
+    rc = f32 ? launch_chain2f(a, bwd, stream) : launch_chain2(a, bwd, stream);
     if (rc) return rc == SOW_ERR_ALIGN ? SOW_ERR_UNSUPPORTED : rc;
   }
   if (nsl == 0) return SOW_OK;
@@ -77,7 +79,7 @@ static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* 
   ChainParams b = p;
   const int kn = want < nsl ? want : nsl;
   b.ntb = ntb, b.st_per = 0, b.sl_per = ceil_div(nsl, kn), b.Hpartial = nullptr, b.Hload = p.Hsave, b.Hsave = nullptr;
-  return launch_chain2(b, bwd, stream);
+  return f32 ? launch_chain2f(b, bwd, stream) : launch_chain2(b, bwd, stream);
 }
 
 // row-major A, plain product: the streaming kernel when it fills the chip, else the 128x128 kernel

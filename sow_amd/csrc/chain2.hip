@@ -487,7 +487,8 @@ bool chain2_supported(const ChainParams& p, int dtype) {
 }
 
 // Hsave[t][c] = bf16(scale * sum_s Hpartial[s][t][c]) for c < rb, 0 above, 1.0 in column 63 when rb < 64
-__global__ __launch_bounds__(256) void h_reduce_kernel(const float* __restrict__ Hp, int nsplit, bf16_t* __restrict__ Hs, int64_t M,
+template <typename T>
+__global__ __launch_bounds__(256) void h_reduce_kernel(const float* __restrict__ Hp, int nsplit, T* __restrict__ Hs, int64_t M,
                                                        int rb, float scale) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 8-column group per thread
   const int64_t tok = idx >> 3;
@@ -500,20 +501,27 @@ __global__ __launch_bounds__(256) void h_reduce_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += a[j], v[4 + j] += b[j];
   }
-  u32x4 out;
-  bf16_t* e = (bf16_t*)&out;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = c0 + j;
-    e[j] = c < rb ? (bf16_t)(v[j] * scale) : ((c == 63 && rb < 64) ? (bf16_t)1.0f : (bf16_t)0.f);
+    v[j] = c < rb ? v[j] * scale : ((c == 63 && rb < 64) ? 1.0f : 0.f);
   }
-  *(u32x4*)(Hs + tok * 64 + c0) = out;
+  if constexpr (sizeof(T) == 2) {
+    *(u32x4*)(Hs + tok * 64 + c0) = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  } else {
+    *(f32x4*)(Hs + tok * 64 + c0) = (f32x4){v[0], v[1], v[2], v[3]};
+    *(f32x4*)(Hs + tok * 64 + c0 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  }
 }
 
-int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, hipStream_t stream) {
+int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, int dtype,
+                    hipStream_t stream) {
   if (M <= 0) return SOW_OK;
-  hipLaunchKernelGGL(h_reduce_kernel, dim3((unsigned)((M * 8 + 255) / 256)), dim3(256), 0, stream, Hpartial, nsplit,
-                     (bf16_t*)Hsave, M, rb, scale);
+  const dim3 grid((unsigned)((M * 8 + 255) / 256));
+  if (dtype == SOW_BF16)
+    hipLaunchKernelGGL(h_reduce_kernel<bf16_t>, grid, dim3(256), 0, stream, Hpartial, nsplit, (bf16_t*)Hsave, M, rb, scale);
+  else
+    hipLaunchKernelGGL(h_reduce_kernel<float>, grid, dim3(256), 0, stream, Hpartial, nsplit, (float*)Hsave, M, rb, scale);
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }

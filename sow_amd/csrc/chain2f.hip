@@ -64,10 +64,17 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int64_t m0 = (int64_t)blockIdx.x * C3_BM;
+  // short-T split (kernels.hpp): workgroup = (token block, split); a split owns a range of phase-1 stages OR of
+  // phase-2 slices.  Without a split every workgroup owns all of both.
+  const int tb = p.ntb > 0 ? (int)blockIdx.x % p.ntb : (int)blockIdx.x;
+  const int split = p.ntb > 0 ? (int)blockIdx.x / p.ntb : 0;
+  const int64_t m0 = (int64_t)tb * C3_BM;
   const int D1 = p.D1, D2 = p.D2, rb = p.rb;
-  const int nst = (D1 + 63) / 64;   // phase-1 chunks = X stages
-  const int nsl = (D2 + 63) / 64;   // phase-2 chunks = output slices
+  const int nst_all = (D1 + 63) / 64, nsl_all = (D2 + 63) / 64;
+  const int st0 = p.st_per > 0 ? split * p.st_per : 0;   // first phase-1 stage of this workgroup
+  const int sl0 = p.sl_per > 0 ? split * p.sl_per : 0;   // first phase-2 slice
+  const int nst = p.sl_per > 0 ? 0 : (p.st_per > 0 ? (nst_all - st0 < p.st_per ? nst_all - st0 : p.st_per) : nst_all);
+  const int nsl = p.st_per > 0 ? 0 : (p.sl_per > 0 ? (nsl_all - sl0 < p.sl_per ? nsl_all - sl0 : p.sl_per) : nsl_all);
   const int total = nst + nsl;
   const float* Amat = (const float*)(BWD ? p.F2b : p.F1b);   // [rows_a, rb] contiguous
   const float* Bmat = (const float*)(BWD ? p.F1b : p.F2b);   // [rb, cols_b], ld = ldb
@@ -91,7 +98,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
     const int rsub = lane >> 4, pc = lane & 15;
     auto issue = [&](int c) {
       char* slot = smem + (c % C3_NSLOT) * C3_FSLOT;
-      const int ci = c < nst ? c : c - nst;
+      const int ci = c < nst ? st0 + c : sl0 + (c - nst);
       if (chunk_is_a(c)) {
 #pragma unroll
         for (int ii = 0; ii < C3_LPW; ++ii) {
@@ -116,7 +123,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c (the only one in flight) has landed
       __builtin_amdgcn_sched_barrier(0);
       if (chunk_is_a(c)) {   // fix-up: rewrite the last row of A (pieces past the end of the buffer were zero-filled)
-        const int base = (c < nst ? c : c - nst) * 64;
+        const int base = (c < nst ? st0 + c : sl0 + (c - nst)) * 64;
         const int lr = rows_a - 1 - base;
         if (own_last && lr >= 0 && lr < 64) {
           const int cc = lane >> 2;
@@ -154,7 +161,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
     const int row = 4 * (C3_XPW * hh + ii) + drow;
     const int lc = dpc ^ (row & 15);
     const int64_t tk = tok0 + row;
-    const int col = st * 64 + 4 * lc;
+    const int col = (st0 + st) * 64 + 4 * lc;
     const void* q = (tk < p.M && col < D1) ? (const void*)(X + tk * p.ldx + col) : (const void*)zp;
     dma16(q, dst + (C3_XPW * hh + ii) * 1024);
   };
@@ -229,6 +236,23 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
   }
 
   // ================================================================== hand-off: sum the two K halves
+  const int64_t tok = tok0 + li;
+  if (p.Hload) {
+    // phase-2-only workgroup: H comes from memory; register `reg` of tile rt is rank rt*32 + (reg&3) + 8(reg>>2) + 4lh
+    // of token li.  The 1.0 of column 63 (dbias trick) must not reach the product.
+    raw_barrier();
+    raw_barrier();
+    const float* Hl = (const float*)p.Hload + tok * 64 + 4 * lh;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tok < p.M) v = *(const f32x4*)(Hl + rt * 32 + 8 * rq);
+        if (rt == 1 && rq == 3 && lh == 1 && rb < 64) v[3] = 0.f;
+        hacc[rt][4 * rq + 0] = v[0], hacc[rt][4 * rq + 1] = v[1], hacc[rt][4 * rq + 2] = v[2], hacc[rt][4 * rq + 3] = v[3];
+      }
+  } else {
   raw_barrier();   // every X read of the workgroup is done: the rings become the exchange buffers
   {
     float* xch = (float*)(smem + C3_RING0) + w * 2048;
@@ -249,9 +273,18 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) hacc[rt][reg] += __builtin_bit_cast(float, pv[rt * 16 + reg]);
   }
+  if (p.Hpartial) {
+    // phase-1 slab of a short-T split: the raw fp32 sums of this K range, one 32-rank tile per half
+    if (tok < p.M) {
+      float* Hp = p.Hpartial + ((int64_t)split * p.M + tok) * 64 + hh * 32 + 4 * lh;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *(f32x4*)(Hp + 8 * rq) = hh ? (f32x4){hacc[1][4 * rq + 0], hacc[1][4 * rq + 1], hacc[1][4 * rq + 2], hacc[1][4 * rq + 3]}
+                                    : (f32x4){hacc[0][4 * rq + 0], hacc[0][4 * rq + 1], hacc[0][4 * rq + 2], hacc[0][4 * rq + 3]};
+    }
+  } else {
   // scale, mask rank rows >= r; the saved copy [M, 64] carries 1.0 in column 63 when free (the dbias
   // trick of the skinny-TN kernel); one 32-rank tile per half, 16-byte pieces.
-  const int64_t tok = tok0 + li;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
@@ -268,6 +301,8 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
         *(f32x4*)(Hs + 8 * rq) = v;
       }
     }
+  }
+  }
   }
   // ================================================================== phase 2: Y^T = F2^T . H^T (column tile hh)
   float* Y = (float*)p.Y;
@@ -286,7 +321,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
   auto flush_store = [&](int sl_prev, int pass) {   // 8 rows of 128 B per pass
     const int r = pass * 8 + (lane >> 3), c = lane & 7;
     const int64_t tk = tok0 + r;
-    const int col = sl_prev * 64 + hh * 32 + 4 * c;
+    const int col = (sl0 + sl_prev) * 64 + hh * 32 + 4 * c;
     if (tk < p.M && col < D2) {
       f32x4 o = fv[pass];
       float* dst = Y + tk * p.ldy + col;
@@ -391,7 +426,11 @@ int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream) {
   const int64_t ldA = bwd ? p.ldf2b : p.ldf1b;
   if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 4 || (reinterpret_cast<uintptr_t>(Ap) & 3) || ldA != p.rb)
     return SOW_ERR_ALIGN;
-  const int grid = ceil_div(p.M, C3_BM);
+  int grid = ceil_div(p.M, C3_BM);
+  if (p.ntb > 0) {
+    const int nsplit = p.st_per > 0 ? ceil_div((p.D1 + 63) / 64, p.st_per) : ceil_div((p.D2 + 63) / 64, p.sl_per);
+    grid = p.ntb * nsplit;
+  }
   if (bwd) {
     SOW_SET_MAX_LDS_ONCE(C3_LDS, chain2f_kernel<true>);
     hipLaunchKernelGGL(chain2f_kernel<true>, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);

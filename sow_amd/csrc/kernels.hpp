@@ -20,7 +20,7 @@ struct ChainParams {
   const void* pad_src;
   void* pad_dst;
   int pad_rows, pad_r;
-  // Short-T split of the bf16 streaming kernel (grid = ntb token blocks x splits; ntb = 0: no split):
+  // Short-T split of the streaming kernels (chain2 / chain2f) (grid = ntb token blocks x splits; ntb = 0: no split):
   //   st_per > 0: workgroup (tb, s) runs phase 1 over stages [s*st_per, ..) only and writes its fp32 partial H to
   //               Hpartial[s][M][64] (no phase 2; h_reduce sums, scales, masks and casts into Hsave);
   //   sl_per > 0: workgroup (tb, s) skips phase 1, takes H from Hload [M, 64] and runs phase 2 over slices
@@ -33,7 +33,8 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
 bool chain2_supported(const ChainParams& p, int dtype);
 int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream);
-int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, hipStream_t stream);
+int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, int dtype,
+                    hipStream_t stream);
 // chain2f.hip (fp32 streaming version)
 bool chain2f_supported(const ChainParams& p, int dtype);
 int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream);
