@@ -177,7 +177,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
       ph.X = x, ph.Y = nullptr, ph.Hsave = h_save, ph.bias = nullptr;
       ph.M = T, ph.ldx = d_in, ph.ldy = d_out, ph.D1 = d_in, ph.D2 = 0;
       ph.F1b = A, ph.ldf1b = r_live, ph.F2b = B, ph.ldf2b = d_out, ph.rb = r_live;
-      ph.scale = scale, ph.beta = 0.f, ph.save_scaled = 0;
+      ph.scale = scale, ph.beta = 0.f;
       if (chain2_supported(ph, dtype) &&
           gemm2_supported(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, y, d_out, bias, T, d_out, d_in, dtype)) {
         rc = launch_chain2(ph, false, stream);
@@ -195,7 +195,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
       p.X = x, p.Y = y, p.Hsave = nullptr, p.bias = nullptr;
       p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
       p.F1b = acc_down, p.ldf1b = r_acc, p.F2b = acc_up, p.ldf2b = d_out, p.rb = r_acc;
-      p.scale = 1.f, p.beta = 0.f, p.save_scaled = 0;
+      p.scale = 1.f, p.beta = 0.f;
       rc = launch_chain(p, dtype, false, stream);
       if (rc) return rc;
       beta = 1.f;
@@ -214,7 +214,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
     p.X = x, p.Y = y, p.Hsave = h_save, p.bias = bias;
     p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
     p.F1b = A, p.ldf1b = r_live, p.F2b = B, p.ldf2b = d_out, p.rb = r_live;
-    p.scale = scale, p.beta = beta, p.save_scaled = 0;
+    p.scale = scale, p.beta = beta;
     if (ws && workspace_bytes >= w.total) {
       rc = launch_chain_short(p, dtype, false, (float*)(ws + w.off_hp), stream);
       if (rc != SOW_ERR_UNSUPPORTED) return rc;
@@ -268,7 +268,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       pd.X = dy, pd.Y = nullptr, pd.Hsave = dh, pd.bias = nullptr;
       pd.M = T, pd.ldx = d_out, pd.ldy = d_in, pd.D1 = d_out, pd.D2 = 0;
       pd.F1b = B, pd.ldf1b = d_out, pd.F2b = A, pd.ldf2b = r_live, pd.rb = r_live;
-      pd.scale = scale, pd.beta = 0.f, pd.save_scaled = 1;
+      pd.scale = scale, pd.beta = 0.f;
       void* apad = ws + w.off_apad;
       if (chain2_supported(pd, dtype) &&
           gemm2_supported(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, dx, d_in, nullptr, T, d_in, d_out, dtype)) {
@@ -298,7 +298,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       p.X = dy, p.Y = dx, p.Hsave = nullptr, p.bias = nullptr;
       p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
       p.F1b = acc_up, p.ldf1b = d_out, p.F2b = acc_down, p.ldf2b = r_acc, p.rb = r_acc;
-      p.scale = 1.f, p.beta = 0.f, p.save_scaled = 0;
+      p.scale = 1.f, p.beta = 0.f;
       rc = launch_chain(p, dtype, true, stream);
       if (rc) return rc;
       beta = 1.f;
@@ -316,7 +316,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     p.X = dy, p.Y = dx, p.Hsave = dh, p.bias = nullptr;
     p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
     p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
-    p.scale = scale, p.beta = beta, p.save_scaled = 1;
+    p.scale = scale, p.beta = beta;
     if (do_data && !data_done) {
       rc = launch_chain_short(p, dtype, true, short_hp_bytes(T, d_in, d_out, r_live, dtype) ? (float*)(ws + w.off_hp) : nullptr, stream);
       if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain(p, dtype, true, stream);

@@ -54,7 +54,6 @@ constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 24 KiB per token group
 constexpr int C2_LDS = C2_RING0 + C2_NTG * C2_RING;   // 80 KiB: two workgroups per CU
 constexpr int C2_THREADS = 64 * (C2_NCW + C2_NLW);
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page2[64];
 
 template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
   return TR ? (c ^ (((row >> 1) & 1) << 2)) : (c ^ ((row >> 1) & 7));
@@ -84,7 +83,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
   const bf16_t* Bmat = (const bf16_t*)(BWD ? p.F1b : p.F2b);   // [rb, cols_b], ld = ldb
   const int64_t ldb = BWD ? p.ldf1b : p.ldf2b;
   const int rows_a = BWD ? D2 : D1, cols_b = BWD ? D1 : D2;
-  const char* zp = (const char*)(g_zero_page2 + (lane & 7) * 4);
+  const char* zp = zero_page_for(lane);
 
   if (w >= C2_NCW) {
     // ------------------------------------------------------------------ loader waves

@@ -58,7 +58,6 @@ constexpr int C3_LDS = C3_RING0 + C3_NTG * C3_RING;    // 80 KiB
 constexpr int C3_THREADS = 64 * (C3_NCW + C3_NLW);
 constexpr int C3_PARK0 = 32768;        // wave-private Y tiles live behind the 32-KiB exchange area
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page4[64];
 
 template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,7 +79,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
   const float* Bmat = (const float*)(BWD ? p.F1b : p.F2b);   // [rb, cols_b], ld = ldb
   const int64_t ldb = BWD ? p.ldf1b : p.ldf2b;
   const int rows_a = BWD ? D2 : D1, cols_b = BWD ? D1 : D2;
-  const char* zp = (const char*)(g_zero_page4 + (lane & 7) * 4);
+  const char* zp = zero_page_for(lane);
 
   if (w >= C3_NCW) {
     // ------------------------------------------------------------------ loader waves

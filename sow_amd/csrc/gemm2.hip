@@ -38,7 +38,6 @@ constexpr int G2_STAGE = 2 * G2_PIECE;          // 32 KiB
 constexpr int G2_LDS = G2_NSLOT * G2_STAGE;     // 128 KiB
 constexpr int G2_DPW = 4;                       // DMA instructions per wave per stage (2 A + 2 B)
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page3[64];
 
 struct Gemm2Params {
   const bf16_t* A;
@@ -65,7 +64,7 @@ template <bool NT> __global__ __launch_bounds__(G2_THREADS, 1) void gemm2_kernel
   const int64_t M = p.M;
   const int s_main = (K + G2_BK - 1) / G2_BK;
   const int S = s_main + (p.A2 ? 2 : 0);
-  const char* zp = (const char*)(g_zero_page3 + (lane & 7) * 4);
+  const char* zp = zero_page_for(lane);
 
   // ---------------------------------------------------------------- DMA sources (per lane)
   // k-contiguous pieces ([256 rows][32 k], 64-byte rows): instruction i = 2w + ii covers rows 16i .. 16i+15

@@ -13,7 +13,6 @@ struct ChainParams {
   int64_t M, ldx, ldy, ldf1a, ldf1b, ldf2a, ldf2b;
   int D1, D2, ra, rb;
   float scale, beta;
-  int save_scaled;
   int fast_factors;
   // side job of the bf16 streaming kernel: out[rows, 64] = [in[rows, r] | 0] (the zero-padded A that the dense
   // backward's K-extension DMAs row by row); workgroup b copies rows 64 b .. 64 b + 63.  nullptr = none.

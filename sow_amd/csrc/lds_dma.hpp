@@ -9,6 +9,11 @@
 
 namespace sow {
 
+// Source of out-of-range DMA lanes: exact zeros (one copy per translation unit).  LDS-DMA has no per-lane
+// predication that still writes the destination, so a lane that must contribute zeros reads from here.
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+__device__ __forceinline__ const char* zero_page_for(int lane) { return (const char*)(g_zero_page + (lane & 7) * 4); }
+
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }

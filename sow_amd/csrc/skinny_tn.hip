@@ -203,7 +203,6 @@ template <typename T> __global__ __launch_bounds__(256, 2) void tn_partial_kerne
 // =================================================================================================
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];  // source of out-of-range DMA lanes
 
 constexpr int TN_DEPTH = 4;                 // 16-token groups in flight per wave
 constexpr int TN_STAGE_BYTES = 4096;        // [16][64] bf16 M tile + [16][64] bf16 S tile
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_kernel(const TnParams p
   // Per-lane running source pointers, advanced by a per-lane constant in issue order (2 VALU per DMA); only a
   // group that crosses t_end takes the checked path.
   const int drow = lane >> 3, dpc = lane & 7;
-  const char* zp = (const char*)(g_zero_page + (lane & 7) * 4);
+  const char* zp = zero_page_for(lane);
   const char* pm[2];
   const char* ps[2];
   int64_t m_step[2];
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnPara
   // this path every non-MFMA instruction is paid for in matrix-pipe time.  Only a group that
   // crosses t_end takes the checked path.
   const int drow = lane >> 4, dpc = lane & 15;   // DMA lane -> (row in a 4-row block, 16-byte chunk)
-  const char* zp = (const char*)(g_zero_page + (lane & 7) * 4);
+  const char* zp = zero_page_for(lane);
   const bool mcol_ok = d0 + dpc * 4 < D;
   const int64_t m_step = mcol_ok ? (int64_t)32 * ldm * 4 : 0;   // 4 waves x 8 tokens per step of this wave
   const int64_t s_step = (int64_t)32 * 64 * 4;
