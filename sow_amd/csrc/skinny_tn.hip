@@ -538,8 +538,19 @@ template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(co
   if (d < J.D) {
     const int64_t stride = (int64_t)J.Dpad * 64;
     const float* src = J.partial + (int64_t)d * 64 + c4;
-    for (int i = split; i < p.ns; i += 4) {
-      const f32x4 v = *(const f32x4*)(src + i * stride);
+    // four loads in flight per thread (the kernel is a chain of dependent round trips otherwise); the summation
+    // order per thread stays i = split, split + 4, ... so the result is unchanged
+    int i = split;
+    for (; i + 12 < p.ns; i += 16) {
+      const f32x4 v0 = *(const f32x4*)(src + (int64_t)i * stride);
+      const f32x4 v1 = *(const f32x4*)(src + (int64_t)(i + 4) * stride);
+      const f32x4 v2 = *(const f32x4*)(src + (int64_t)(i + 8) * stride);
+      const f32x4 v3 = *(const f32x4*)(src + (int64_t)(i + 12) * stride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = (((s[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
+    }
+    for (; i < p.ns; i += 4) {
+      const f32x4 v = *(const f32x4*)(src + (int64_t)i * stride);
       s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
     }
   }
