@@ -585,7 +585,8 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len) {
   const int bt = dtype == SOW_F32 ? TnCfg<float>::BT : TnCfg<bf16_t>::BT;
   // Two workgroups per CU are resident (64 KiB of LDS each), 512 in all; slabs stay >= 512 tokens so the
   // partial traffic (ns * D * 64 * 4 bytes) is a small fraction of the streamed operand.
-  //   bf16 (HBM-bound): ~512 blocks rounded UP to a multiple of 8 slabs -- the column groups of one slab then
+  //   bf16 (HBM-bound): a multiple of 8 slabs giving one round when that keeps >= 90 % of the slots (30 column
+  //     groups -> 16 slabs, 480 blocks), else ~512 blocks rounded UP to a multiple of 8 slabs -- the column groups of one slab then
   //     share an XCD and S is served from that L2; the small second round is hidden by the memory system
   //     (measured: 576 blocks 25.9 us vs 504 blocks 28.1 us at d = 768).
   //   fp32 (MFMA-bound): AT MOST 512 blocks -- a 13 % overshoot is a second, nearly empty round on a saturated
@@ -600,6 +601,8 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len) {
     if (ns > 8 && (ns & ~7) * 10 >= ns * 9) ns &= ~7;
   } else {
     ns = (512 + total_colgroups - 1) / total_colgroups;
+    const int ns_down = (512 / total_colgroups) & ~7;   // single round AND a multiple of 8, when it keeps >= 90 % of the slots
+    if (ns_down >= 8 && ns_down * total_colgroups * 10 >= 512 * 9) ns = ns_down;
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
     if (ns > 8) ns = (ns + 7) & ~7;
