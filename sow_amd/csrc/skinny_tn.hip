@@ -13,6 +13,7 @@
 // from that XCD's L2 after the first read.
 #include "kernels.hpp"
 #include "lds_dma.hpp"
+#include <cstdlib>
 
 namespace sow {
 
@@ -370,6 +371,169 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_kernel(const TnParams p
 }
 
 // =================================================================================================
+// bf16 wide variant: 8 waves, TWO 64-column groups of M per workgroup.
+//
+// With one column group per block the S stream (h / dh rows, served by L2) is as large as the M stream (HBM):
+// 134 MB of LDS-DMA for 67 MB of HBM on a 512/512 layer, and the kernel is bound by the DMA path as a whole.
+// Here every wave streams [16 tok x 128 col] of M and [16 tok x 64] of S per group (6 KiB, 4 + 2 DMA
+// instructions, 3 ring slots), i.e. half the S bytes per M byte; 8 waves (group g -> wave g % 8) keep the slab count
+// -- and with it the fp32 partial traffic -- where it was.  144 KiB of LDS, one workgroup per CU.
+// =================================================================================================
+constexpr int TNW_DEPTH = 3;
+constexpr int TNW_STAGE_BYTES = 6144;       // [16][64] bf16 M tile x 2 + [16][64] bf16 S tile
+constexpr int TNW_WAVES = 8;
+
+__device__ __forceinline__ void tnw_wait_stages(int newer) {   // 6 DMA instructions per stage
+  switch (newer) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+__global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int b = blockIdx.x, jid = 0;
+  const int ncg2_0 = (p.job[0].ncg + 1) / 2;
+  if (p.njobs > 1 && b >= ncg2_0 * p.ns) {
+    b -= ncg2_0 * p.ns;
+    jid = 1;
+  }
+  const bf16_t* Mg = (const bf16_t*)(jid ? p.job[1].M : p.job[0].M);
+  const bf16_t* Sg = (const bf16_t*)(jid ? p.job[1].S : p.job[0].S);
+  float* Pg = jid ? p.job[1].partial : p.job[0].partial;
+  const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
+  const int D = jid ? p.job[1].D : p.job[0].D;
+  const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
+  const int dcg = b / p.ns, slab = b % p.ns;
+  const int d0 = dcg * 2 * TN_BD;
+  const int64_t t_begin = (int64_t)slab * p.slab_len;
+  int64_t t_end = t_begin + p.slab_len;
+  if (t_end > p.T) t_end = p.T;
+  char* ring = smem + w * (TNW_DEPTH * TNW_STAGE_BYTES);
+
+  const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 15) / 16) : 0;
+  const int nw = ngroups > w ? (ngroups - w + TNW_WAVES - 1) / TNW_WAVES : 0;  // groups of this wave
+
+  // DMA sources: instruction q = 2 * tile + half (tile 0, 1 = the two M column groups, tile 2 = S); running per-lane
+  // pointers as in the narrow kernel
+  const int drow = lane >> 3, dpc = lane & 7;
+  const char* zp = zero_page_for(lane);
+  const char* ptr[6];
+  int64_t step[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int tile = q >> 1, half = q & 1;
+    const int row = half * 8 + drow;
+    const int lc = dpc ^ (((row >> 1) & 1) << 2);
+    const int64_t tt = t_begin + (int64_t)w * 16 + row;
+    if (tile < 2) {
+      const bool ok = d0 + tile * TN_BD + lc * 8 < D;
+      ptr[q] = ok ? (const char*)(Mg + tt * ldm + d0 + tile * TN_BD + lc * 8) : zp;
+      step[q] = ok ? (int64_t)TNW_WAVES * 16 * ldm * 2 : 0;
+    } else {
+      ptr[q] = (const char*)(Sg + tt * 64 + lc * 8);
+      step[q] = (int64_t)TNW_WAVES * 16 * 64 * 2;
+    }
+  }
+  auto issue = [&](int i) {
+    const int64_t tt0 = t_begin + (int64_t)(w + TNW_WAVES * i) * 16;
+    char* slot = ring + (i % TNW_DEPTH) * TNW_STAGE_BYTES;
+    const bool whole = tt0 + 16 <= t_end;   // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const void* src = ptr[q];
+      if (!whole && tt0 + (q & 1) * 8 + drow >= t_end) src = zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
+      ptr[q] += step[q];
+    }
+  };
+
+  f32x16 acc[4][2];   // [2 * column group + row tile][S tile]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+
+  const int g = lane >> 4, jj = lane & 15, q4 = jj >> 2, pp = jj & 3, h = g >> 1;
+  uint32_t roff[2];   // [tile within a [16][64] image] byte offset of the read of rows 8h + q (+512: rows 8h + 4 + q)
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    const int row = 8 * h + q4;
+    const int col = tile * 32 + 16 * (g & 1) + 4 * pp;
+    const int pc = (col >> 3) ^ (((row >> 1) & 1) << 2);
+    roff[tile] = (uint32_t)(row * 128 + pc * 16 + (col & 7) * 2);
+  }
+
+  const uint32_t ring_addr = lds_addr(ring);
+  const int pre = nw < TNW_DEPTH ? nw : TNW_DEPTH;
+  for (int i = 0; i < pre; ++i) issue(i);
+  for (int i = 0; i < nw; ++i) {
+    const int newer = (nw - 1 - i) < (TNW_DEPTH - 1) ? (nw - 1 - i) : (TNW_DEPTH - 1);
+    tnw_wait_stages(newer);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t sa = ring_addr + (uint32_t)((i % TNW_DEPTH) * TNW_STAGE_BYTES);
+    u32x2 ml[4], mh[4], sl[2], sh[2];   // M: [2 * column group + row tile]; S: [tile]; low / high k half
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint32_t ad = sa + (uint32_t)((a >> 1) * 2048) + roff[a & 1];
+      DS_READ_TR(ml[a], ad, 0);
+      DS_READ_TR(mh[a], ad, 512);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t ad = sa + 4096u + roff[c];
+      DS_READ_TR(sl[c], ad, 0);
+      DS_READ_TR(sh[c], ad, 512);
+    }
+    LGKM_WAIT0();
+    bf16x8 bfr[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bfr[c] = as_bf16x8(join2(sl[c], sh[c]));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bf16x8 af = as_bf16x8(join2(ml[a], mh[a]));
+      acc[a][0] = mfma32(af, bfr[0], acc[a][0]);
+      acc[a][1] = mfma32(af, bfr[1], acc[a][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + TNW_DEPTH < nw) issue(i + TNW_DEPTH);   // the slot's reads have returned: refill it
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // cross-wave sum of the eight [64][64] fp32 partials of each column group through LDS (aliases the rings)
+  float* red = (float*)smem;  // [8 waves][64][64]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (2 * dcg + half >= ncg) break;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          red[w * 4096 + (a * 32 + acc_row(reg, lane)) * 64 + c * 32 + (lane & 31)] = acc[2 * half + a][c][reg];
+    __syncthreads();
+    float* P = Pg + ((int64_t)slab * ncg * TN_BD + d0 + half * TN_BD) * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int v = t + 512 * it;  // 1024 float4 of the [64][64] tile
+      f32x4 s0 = *(const f32x4*)(red + v * 4);
+#pragma unroll
+      for (int k = 1; k < TNW_WAVES; ++k) s0 += *(const f32x4*)(red + k * 4096 + v * 4);
+      *(f32x4*)(P + v * 4) = s0;
+    }
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
 // fp32 fast path: the same wave-private LDS-DMA rings with exact-fp32 MFMA (32x32x2).
 //
 // fp32 needs no transposed reads: the MFMA takes ONE token per lane-half, and with the tiles in their
@@ -629,7 +793,13 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
       dma = dma && J.D % 8 == 0 && J.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
     }
-    if (dma) {
+    if (dma && !getenv("SOW_AMD_TN_NARROW")) {
+      constexpr int LDS = TNW_WAVES * TNW_DEPTH * TNW_STAGE_BYTES;  // 144 KiB (rings; reused by the cross-wave sum)
+      SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
+      int blocks2 = 0;   // two 64-column groups per block
+      for (int j = 0; j < p.njobs; ++j) blocks2 += (p.job[j].ncg + 1) / 2 * p.ns;
+      hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3(blocks2), dim3(64 * TNW_WAVES), LDS, stream, p);
+    } else if (dma) {
       constexpr int LDS = 4 * TN_DEPTH * TN_STAGE_BYTES;  // 64 KiB (rings; reused by the cross-wave sum)
       SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_kernel);
       hipLaunchKernelGGL(tn_partial_dma_kernel, dim3(blocks), dim3(256), LDS, stream, p);
