@@ -127,8 +127,8 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   w.off_hp = off;     // fp32 partial H of the short-T split: splits * T * 64 floats, splits <= 256 / ceil(T / 64)
   off += short_hp_bytes(T, d_in, d_out, r_live, dtype);
   if (r_live <= 64) {
-    const int cg = (d_in + 63) / 64 + (d_out + 63) / 64;
-    w.ns = tn_pick_slabs(T, cg, dtype, &w.slab_len);
+    const int cg_in = (d_in + 63) / 64, cg_out = (d_out + 63) / 64;
+    w.ns = tn_pick_slabs(T, cg_in + cg_out, (cg_in + 1) / 2 + (cg_out + 1) / 2, dtype, &w.slab_len);
     w.off_p0 = off;
     off += al256(tn_partial_bytes(w.ns, d_in));
     w.off_p1 = off;

@@ -72,7 +72,8 @@ struct ReduceParams {
   int ns;
   int blocks0;
 };
-int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len);
+// total_colgroups = 64-column groups over both jobs; total_colgroup_pairs = the same in pairs, rounded up per job
+int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len);
 size_t tn_partial_bytes(int ns, int D);
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
 int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);

@@ -745,14 +745,11 @@ template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(co
 }
 
 // ---------------------------------------------------------------------------------------------
-int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len) {
+int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len) {
   const int bt = dtype == SOW_F32 ? TnCfg<float>::BT : TnCfg<bf16_t>::BT;
   // Two workgroups per CU are resident (64 KiB of LDS each), 512 in all; slabs stay >= 512 tokens so the
   // partial traffic (ns * D * 64 * 4 bytes) is a small fraction of the streamed operand.
-  //   bf16 (HBM-bound): a multiple of 8 slabs giving one round when that keeps >= 90 % of the slots (30 column
-  //     groups -> 16 slabs, 480 blocks), else ~512 blocks rounded UP to a multiple of 8 slabs -- the column groups of one slab then
-  //     share an XCD and S is served from that L2; the small second round is hidden by the memory system
-  //     (measured: 576 blocks 25.9 us vs 504 blocks 28.1 us at d = 768).
+  //   bf16 (HBM-bound): see below; a multiple of 8 keeps the column groups of one slab on one XCD (S from that L2).
   //   fp32 (MFMA-bound): AT MOST 512 blocks -- a 13 % overshoot is a second, nearly empty round on a saturated
   //     matrix pipe (measured: 576 blocks 93 us vs 504 blocks 74 us).
   int ns;
@@ -764,12 +761,14 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int dtype, int* slab_len) {
     if (ns < 1) ns = 1;
     if (ns > 8 && (ns & ~7) * 10 >= ns * 9) ns &= ~7;
   } else {
-    ns = (512 + total_colgroups - 1) / total_colgroups;
-    const int ns_down = (512 / total_colgroups) & ~7;   // single round AND a multiple of 8, when it keeps >= 90 % of the slots
-    if (ns_down >= 8 && ns_down * total_colgroups * 10 >= 512 * 9) ns = ns_down;
+    // the wide kernel owns two column groups per block and one 8-wave workgroup per CU: the largest multiple of 8
+    // that keeps the grid within ONE round of 256 (measured at d = 768, 12 double groups: 16 slabs / 192 blocks
+    // 22.2 us, 21 / 252 26.9 us, 24 / 288 30.5 us; llama_60m: 32 slabs for 512/512, 16 for the 1376-wide layers)
+    const int cg2 = total_colgroup_pairs > 0 ? total_colgroup_pairs : 1;
+    ns = (256 / cg2) & ~7;
+    if (ns < 8) ns = 256 / cg2;
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
-    if (ns > 8) ns = (ns + 7) & ~7;
   }
   int64_t len = (T + ns - 1) / ns;
   len = (len + bt - 1) / bt * bt;
