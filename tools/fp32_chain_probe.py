@@ -1,3 +1,4 @@
+"""Driver for rocprofv3 --kernel-trace runs of the fp32 streaming chain at the north-star point (summarise with tools/kstats.py)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sow_amd import ops
