@@ -173,6 +173,11 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
   if (acc_kind == SOW_ACC_DENSE) {
     if (r_live <= 64 && h_save) {
       // one product with the low-rank term as a K-extension:  y = [x, h] . [W_acc; B] + bias,  h = scale * x . A
+      // -- in one launch (h projected inside the GEMM) when d_out spans at most two column tiles
+      if (gemm2h_supported(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in,
+                           r_live, dtype))
+        return launch_gemm2h(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in,
+                             r_live, scale, stream);
       ChainParams ph{};
       ph.X = x, ph.Y = nullptr, ph.Hsave = h_save, ph.bias = nullptr;
       ph.M = T, ph.ldx = d_in, ph.ldy = d_out, ph.D1 = d_in, ph.D2 = 0;
@@ -270,7 +275,14 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       pd.F1b = B, pd.ldf1b = d_out, pd.F2b = A, pd.ldf2b = r_live, pd.rb = r_live;
       pd.scale = scale, pd.beta = 0.f;
       void* apad = ws + w.off_apad;
-      if (chain2_supported(pd, dtype) &&
+      if (gemm2h_supported(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out,
+                           r_live, dtype)) {
+        // one launch: dh projected inside the GEMM, A^T read from A's own 2r-byte rows
+        rc = launch_gemm2h(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out,
+                           r_live, scale, stream);
+        if (rc) return rc;
+        data_done = true;
+      } else if (chain2_supported(pd, dtype) &&
           gemm2_supported(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, dx, d_in, nullptr, T, d_in, d_out, dtype)) {
         // A zero-padded to 64 columns rides along in the dh launch when that grid is large enough
         const bool pad_fused = (int64_t)ceil_div(T, 64) * 64 >= d_in;

@@ -164,6 +164,61 @@ def test_streaming_kernels_agree_with_generic_kernels(monkeypatch, dtype):
     assert torch.equal(h2.view(T, 64)[:, 63].float().cpu(), torch.ones(T)) and float(h2.view(T, 64)[:, 50:63].abs().max()) == 0.0
 
 
+FUSED_H = [
+    # T, d_in, d_out, r, bias      (bf16, dense accumulator; >= 160 output tiles and N <= 512 select gemm2h)
+    (20500, 512, 512, 50, True),    # llama_60m attention shape: forward and backward fused, ragged token tail, 1 fix-up dword
+    (20500, 776, 264, 34, False),   # forward fused (ragged second column tile, K tail of 8); backward N = 776 stays unfused
+    (41000, 256, 512, 44, True),    # backward with a single column tile; 2 fix-up dwords
+    (20500, 512, 504, 46, False),   # 3 fix-up dwords, N % 64 != 0
+    (20500, 512, 512, 48, True),    # r % 8 == 0: no straddling piece
+    (20500, 384, 512, 64, False),   # r = 64: no ones column
+    (20500, 512, 384, 4, False),    # r = 4: smallest fused rank (a 16-byte piece spans two rows of A)
+    (20500, 512, 384, 2, False),    # r = 2: not fused (falls back to GEMM + generic chain)
+]
+
+
+@pytest.mark.parametrize("idx", range(len(FUSED_H)))
+def test_dense_layer_with_in_kernel_projection(idx, monkeypatch):
+    """gemm2h (projection h = s x A computed inside the dense GEMM, one launch per pass) against the oracle and against
+    the two-launch path (H-only chain + K-extended GEMM).  The last row of A is spiked so that a missing fix-up of its
+    straddling 16-byte piece (the only piece whose tail crosses the end of the buffer) cannot hide in the tolerance."""
+    from sow_amd import ops
+    T, d_in, d_out, r, bias = FUSED_H[idx]
+    scale = 0.75
+    x, dy, A, B, b, ad, _ = _rand_case(T, d_in, d_out, r, "dense", bias, 4321 + idx)
+    A = A.clone()
+    A[-1] *= 30.0
+    cast = lambda t: None if t is None else t.to(torch.bfloat16)
+    xq, dyq, Aq, Bq, bq, adq = map(cast, (x, dy, A, B, b, ad))
+    f = lambda t: None if t is None else t.float()
+    y_ref = O.sow_forward(f(xq), [f(Aq)], [f(Bq)], f(adq), None, scale, f(bq))
+    dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(f(dyq), f(xq), [f(Aq)], [f(Bq)], f(adq), None, scale, bias)
+    g = lambda t: None if t is None else t.to(DEV)
+    y, h = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
+    dx, dA, dB, db = ops.sow_backward(g(dyq), g(xq), h, g(Aq), g(Bq), g(adq), None, scale, bias)
+    monkeypatch.setenv("SOW_AMD_NO_FUSED_H", "1")
+    y0, h0 = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
+    dx0, dA0, dB0, db0 = ops.sow_backward(g(dyq), g(xq), h0, g(Aq), g(Bq), g(adq), None, scale, bias)
+    monkeypatch.delenv("SOW_AMD_NO_FUSED_H")
+    tol = 2e-2
+    assert rel_err(y.float().cpu(), y_ref) < tol and rel_err(dx.float().cpu(), dx_ref) < tol
+    assert rel_err(dA.float().cpu(), dA_ref[0]) < tol and rel_err(dB.float().cpu(), dB_ref[0]) < tol
+    if bias:
+        assert rel_err(db.float().cpu(), db_ref) < tol
+    # the column of dX that the last row of A feeds, and the ranks of h its straddling piece holds
+    assert rel_err(dx.float().cpu()[:, -1], dx_ref[:, -1]) < tol
+    hv, h0v = h.view(T, 64).float().cpu(), h0.view(T, 64).float().cpu()
+    h_ref = scale * (f(xq) @ f(Aq))
+    lo = (r // 8) * 8 if r % 8 else r - 8
+    assert rel_err(hv[:, lo:r], h_ref[:, lo:r]) < 1e-2
+    assert rel_err(hv[:, :r], h0v[:, :r]) < 1e-2 and rel_err(y.float().cpu(), y0.float().cpu()) < 1e-2
+    assert rel_err(dx.float().cpu(), dx0.float().cpu()) < 1e-2
+    if r < 64:
+        assert torch.equal(hv[:, 63], torch.ones(T))
+        if r < 63:
+            assert float(hv[:, r:63].abs().max()) == 0.0
+
+
 def test_backward_phases_split_equals_fused():
     """sow_backward_ex: DATA then WEIGHTS on the same workspace == the fused call (bit-exact)."""
     from sow_amd import _lib, ops

@@ -1,6 +1,6 @@
 """Race screen: the kernels are deterministic by construction (fixed reduction orders, no float atomics), so repeated
 launches on the same inputs must be BIT-identical; a difference means a missing wait / barrier somewhere in the
-LDS-DMA pipelines.  Runs every streaming path (chain2, chain2f, skinny-TN, streaming GEMM, short-T split) many times."""
+LDS-DMA pipelines.  Runs every streaming path (chain2, chain2f, skinny-TN, streaming GEMM with and without the in-kernel projection, short-T split) many times."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sow_amd import ops
@@ -9,7 +9,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = 0
 for dtype in (torch.bfloat16, torch.float32):
     for (T, di, do, r, acc) in ((32768, 512, 512, 50, None), (32768, 512, 1376, 50, None), (32768, 1376, 512, 50, None),
-                                (32768, 512, 1376, 50, "dense"), (16500, 776, 1000, 50, "dense"), (4100, 776, 1000, 62, None),
+                                (32768, 512, 1376, 50, "dense"), (16500, 776, 1000, 50, "dense"),
+                                (32768, 512, 512, 50, "dense"), (20500, 776, 264, 34, "dense"), (32768, 1376, 512, 46, "dense"), (4100, 776, 1000, 62, None),
                                 (1000, 4096, 1024, 8, None), (1024, 2048, 4096, 8, "dense"), (8192, 768, 3072, 8, None)):
         g = torch.Generator(device=dev).manual_seed(T + di)
         x = torch.randn(T, di, device=dev, generator=g).to(dtype)
