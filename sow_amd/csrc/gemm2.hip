@@ -265,6 +265,11 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   const int64_t tiles = (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+  // long K: the one-wave-per-SIMD kernel (gemm3.hip) is 7-19 % faster from K ~ 2048 on (4096^3: 1.05 vs 0.90-0.96 PF);
+  // at the llama_60m widths (K <= 1376) the two are level or this one is ahead.  SOW_AMD_GEMM3=1 / =0 force either.
+  const char* g3 = getenv("SOW_AMD_GEMM3");
+  if (g3 ? (g3[0] != '0') : (K >= 2048))
+    return launch_gemm3(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
   if (nt) {
     SOW_SET_MAX_LDS_ONCE(G2_LDS, gemm2_kernel<true>);
     hipLaunchKernelGGL(gemm2_kernel<true>, dim3((unsigned)tiles), dim3(G2_THREADS), G2_LDS, stream, p);

@@ -88,6 +88,10 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                  float alpha, float beta, hipStream_t stream);
 int launch_pad64(const void* in, void* out, int rows, int r, hipStream_t stream);
+// gemm3.hip (same contract as launch_gemm2; one wave per SIMD, 128x128 per wave, hand-interleaved k-loop: long K)
+int launch_gemm3(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                 const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                 float alpha, float beta, hipStream_t stream);
 // gemm2h.hip (the same product with the projection h = hscale * X . op(F) computed in the kernel: one launch per pass)
 bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
                       const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,

@@ -396,13 +396,17 @@ def test_gemm(dtype, ta, tb):
         assert rel_err(out.float().cpu(), ref) < (TOL if dtype == torch.float32 else 2e-2), (M, N, K)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave"])
 @pytest.mark.parametrize("tb", [False, True])
-def test_gemm_streaming_bf16(tb):
-    """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernel: ragged M / N tiles, K tails of 8
-    and 32, alpha / beta / bias epilogue."""
+def test_gemm_streaming_bf16(tb, kernel, monkeypatch):
+    """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernels (gemm2: 8 waves, K < 2048; gemm3: one
+    wave per SIMD, K >= 2048; SOW_AMD_GEMM3 forces either on every shape): ragged M / N tiles, K tails of 8 and 32,
+    one- and two-stage K, alpha / beta / bias epilogue."""
     from sow_amd import ops
+    if kernel != "auto":
+        monkeypatch.setenv("SOW_AMD_GEMM3", "1" if kernel == "1wave" else "0")
     gen = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40)):
+    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40), (2100, 4500, 2056)):
         a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
         b = (torch.randn((N, K) if tb else (K, N), generator=gen) * 0.1).to(torch.bfloat16)
         c0 = torch.randn(M, N, generator=gen).to(torch.bfloat16)
