@@ -185,7 +185,10 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
       ph.scale = scale, ph.beta = 0.f;
       if (chain2_supported(ph, dtype) &&
           gemm2_supported(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, y, d_out, bias, T, d_out, d_in, dtype)) {
-        rc = launch_chain2(ph, false, stream);
+        // short T: the H-only pass split over K (T / 64 workgroups cannot fill the chip: 29 us on 16 workgroups at 1024 x 4096)
+        rc = SOW_ERR_UNSUPPORTED;
+        if (ws && workspace_bytes >= w.total) rc = launch_chain_short(ph, dtype, false, (float*)(ws + w.off_hp), stream);
+        if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain2(ph, false, stream);
         if (rc) return rc;
         return launch_gemm2(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, r_live, y, d_out, bias, T, d_out, d_in,
                             1.f, 0.f, stream);
@@ -287,7 +290,9 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
         // A zero-padded to 64 columns rides along in the dh launch when that grid is large enough
         const bool pad_fused = (int64_t)ceil_div(T, 64) * 64 >= d_in;
         if (pad_fused) pd.pad_src = A, pd.pad_dst = apad, pd.pad_rows = d_in, pd.pad_r = r_live;
-        rc = launch_chain2(pd, true, stream);
+        rc = SOW_ERR_UNSUPPORTED;
+        if (short_hp_bytes(T, d_in, d_out, r_live, dtype)) rc = launch_chain_short(pd, dtype, true, (float*)(ws + w.off_hp), stream);
+        if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain2(pd, true, stream);
         if (rc) return rc;
         if (!pad_fused) {
           rc = launch_pad64(A, apad, d_in, r_live, stream);

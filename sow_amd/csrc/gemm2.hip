@@ -240,9 +240,12 @@ bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
                      const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                      int dtype) {
   if (dtype != SOW_BF16 || !A || !B || !C) return false;
-  // one 256x256 tile per CU: below ~160 tiles (256 CUs) the 128x128 kernel fills the chip better (measured at the
-  // finetune shapes of configs 4-5, tools/gemm_probe2.py: 172 tiles 143 us vs 206 us, 96 tiles 99 us vs 60 us)
-  if (N < 64 || K < 32 || (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160) return false;
+  // one 256x256 tile per CU: below ~160 tiles the 128x128 tiles of gemm3s.hip fill the chip better (launch_gemm2
+  // picks the kernel); below ~96 of those, or with a short K, the generic kernel is as good
+  if (N < 64 || K < 32) return false;
+  if ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160 &&
+      ((int64_t)ceil_div(M, 128) * ceil_div(N, 128) < 96 || K < 512 || getenv("SOW_AMD_NO_GEMM3S")))
+    return false;
   if (getenv("SOW_AMD_FORCE_GEMM_V1")) return false;      // A/B switch, as SOW_AMD_FORCE_CHAIN_V1
   if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return false;
   if (!g2_al16(A) || !g2_al16(B) || !g2_al16(C) || (bias && !g2_al16(bias))) return false;
@@ -265,6 +268,9 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   const int64_t tiles = (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+  const char* gs = getenv("SOW_AMD_GEMM3S");
+  if (gs ? (gs[0] != '0') : ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160))
+    return launch_gemm3s(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
   // long K: the one-wave-per-SIMD kernel (gemm3.hip) is 7-19 % faster from K ~ 2048 on (4096^3: 1.05 vs 0.90-0.96 PF);
   // at the llama_60m widths (K <= 1376) the two are level or this one is ahead.  SOW_AMD_GEMM3=1 / =0 force either.
   const char* g3 = getenv("SOW_AMD_GEMM3");

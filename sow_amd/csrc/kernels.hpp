@@ -99,6 +99,10 @@ bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bo
 int launch_gemm2h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
                   const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
                   int r, float hscale, hipStream_t stream);
+// gemm3s.hip (same contract; 128x128 tiles for products with few 256x256 tiles: short M)
+int launch_gemm3s(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                  float alpha, float beta, hipStream_t stream);
 // qr.hip
 int launch_cast_copy(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
                      int cols, hipStream_t stream);

@@ -78,6 +78,7 @@ SHAPES = [
     (4100, 512, 1376, 50, "dense", True),     # dense accumulator + bias below the streaming GEMM's tile threshold: GEMM + chain (beta = 1)
     (16500, 776, 1000, 50, "dense", True),    # dense accumulator + bias: streaming GEMM with K-extension (>= 160 tiles both ways), ragged M / N tiles, K tails of 8
     (5000, 264, 72, 50, "lowrank", True),     # widths that are not multiples of 64
+    (1100, 2304, 8200, 8, "dense", True),     # finetune-like: short T, long K -> one-wave-per-SIMD streaming GEMM (gemm3) with the K-extension
 ]
 
 
@@ -396,17 +397,20 @@ def test_gemm(dtype, ta, tb):
         assert rel_err(out.float().cpu(), ref) < (TOL if dtype == torch.float32 else 2e-2), (M, N, K)
 
 
-@pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave"])
+@pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave", "small"])
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_streaming_bf16(tb, kernel, monkeypatch):
     """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernels (gemm2: 8 waves, K < 2048; gemm3: one
     wave per SIMD, K >= 2048; SOW_AMD_GEMM3 forces either on every shape): ragged M / N tiles, K tails of 8 and 32,
     one- and two-stage K, alpha / beta / bias epilogue."""
     from sow_amd import ops
-    if kernel != "auto":
+    if kernel == "small":
+        monkeypatch.setenv("SOW_AMD_GEMM3S", "1")     # 128x128-tile kernel (gemm3s) on every shape
+    elif kernel != "auto":
+        monkeypatch.setenv("SOW_AMD_GEMM3S", "0")
         monkeypatch.setenv("SOW_AMD_GEMM3", "1" if kernel == "1wave" else "0")
     gen = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40), (2100, 4500, 2056)):
+    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40), (2100, 4500, 2056), (1000, 2056, 2304)):
         a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
         b = (torch.randn((N, K) if tb else (K, N), generator=gen) * 0.1).to(torch.bfloat16)
         c0 = torch.randn(M, N, generator=gen).to(torch.bfloat16)
