@@ -54,7 +54,7 @@ def parse():
                          "through the module-swap surface (prepare_sow, autograd, AdamW, accumulate), secondary figure")
     ap.add_argument("--accumulate-every", type=int, default=4, help="--mode train: SoW accumulation period in steps")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2: weight-gradient kernels on a side stream (measured: no gain, the kernels are HBM-bound)")
+                    help="2: weight-gradient kernels on a side stream (measured: -4 %%; only their small reduction on a side stream: -16 %% -- cross-stream edges of a HIP graph cost more than the 5-us kernel they hide)")
     return ap.parse_args()
 
 

@@ -85,9 +85,15 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
  *   SOW_BWD_DATA    : dX and the internal dh = scale * dY @ B^T (kept in `workspace`)
  *   SOW_BWD_WEIGHTS : dA, dB, dbias from x, dY, h_save and the dh left in the SAME workspace by a
  *                     preceding SOW_BWD_DATA call (the caller orders the two calls, e.g. with an event).
+ * SOW_BWD_WEIGHTS = SOW_BWD_WEIGHTS_PARTIAL (the token-slab partial sums, left in `workspace`) followed by
+ * SOW_BWD_WEIGHTS_REDUCE (their fixed-order sum into dA / dB / dbias); the two may also be requested separately, e.g.
+ * to run the small reduction beside the next layer's kernels (r_live <= 64; for wider ranks PARTIAL does everything
+ * and REDUCE nothing).
  * phases = SOW_BWD_DATA | SOW_BWD_WEIGHTS is sow_backward. */
 #define SOW_BWD_DATA 1
 #define SOW_BWD_WEIGHTS 2
+#define SOW_BWD_WEIGHTS_PARTIAL 4
+#define SOW_BWD_WEIGHTS_REDUCE 8
 int sow_backward_ex(const void* dy, const void* x, const void* h_save, const void* A, const void* B,
                     const void* acc_down, const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T,
                     int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsow_amd.so")
 F32, BF16 = 0, 1
 ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2
 H_COLS = 64
-BWD_DATA, BWD_WEIGHTS = 1, 2
+BWD_DATA, BWD_WEIGHTS, BWD_WEIGHTS_PARTIAL, BWD_WEIGHTS_REDUCE = 1, 2, 4, 8
 
 # name -> (restype, argtypes); mirrors include/sow_amd.h one to one
 SIGNATURES = {

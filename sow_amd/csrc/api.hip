@@ -241,7 +241,10 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
                     int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype, void* workspace,
                     size_t workspace_bytes, int phases, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  const bool do_data = (phases & SOW_BWD_DATA) != 0, do_weights = (phases & SOW_BWD_WEIGHTS) != 0;
+  const bool do_data = (phases & SOW_BWD_DATA) != 0;
+  const bool do_partial = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_PARTIAL)) != 0;
+  const bool do_reduce = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_REDUCE)) != 0;
+  const bool do_weights = do_partial || do_reduce;
   if (!do_data && !do_weights) return SOW_ERR_SHAPE;
   if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
@@ -352,8 +355,11 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     tp.job[0] = TnJob{x, dh, (float*)(ws + w.off_p0), (int64_t)d_in, d_in, -1, (d_in + 63) / 64, vec_ok(x, d_in), 1};
     tp.job[1] = TnJob{dy, h_save, (float*)(ws + w.off_p1), (int64_t)d_out, d_out, ones_ok ? 63 : -1, (d_out + 63) / 64,
                       vec_ok(dy, d_out), 1};
-    rc = launch_tn(tp, dtype, stream);
-    if (rc) return rc;
+    if (do_partial) {
+      rc = launch_tn(tp, dtype, stream);
+      if (rc) return rc;
+    }
+    if (!do_reduce) return SOW_OK;
     ReduceParams rp{};
     rp.njobs = 2, rp.ns = w.ns;
     rp.job[0] = ReduceJob{(const float*)(ws + w.off_p0), dA, nullptr, (int64_t)r_live, d_in, (d_in + 63) / 64 * 64, r_live, 0, -1,
@@ -378,7 +384,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     rc = launch_gemm(dh, r_live, false, A, r_live, true, dx, d_in, nullptr, T, d_in, r_live, 1.f, beta, dtype, stream);
     if (rc) return rc;
   }
-  if (!do_weights) return SOW_OK;
+  if (!do_partial) return SOW_OK;   // wide ranks: the PARTIAL phase does all of the weight gradients
   rc = launch_gemm(x, d_in, true, dh, r_live, false, dA, r_live, nullptr, d_in, r_live, (int)T, 1.f, grad_beta, dtype, stream);
   if (rc) return rc;
   rc = launch_gemm(h_save, r_live, true, dy, d_out, false, dB, d_out, nullptr, r_live, d_out, (int)T, scale, grad_beta, dtype, stream);

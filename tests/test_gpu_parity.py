@@ -239,6 +239,17 @@ def test_backward_phases_split_equals_fused():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         assert torch.equal(dx, ref[0]) and torch.equal(outs[0], ref[1]) and torch.equal(outs[1], ref[2]) and torch.equal(outs[2], ref[3])
+        # three calls: DATA, the slab partials, their reduction (the last one on another stream)
+        outs3 = (torch.zeros_like(ref[1]), torch.zeros_like(ref[2]), torch.zeros_like(ref[3]))
+        dx3 = torch.empty(T, di, dtype=dtype, device=DEV)
+        kw = dict(out=outs3, dx=dx3, workspace=ws)
+        ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, True, phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL, **kw)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, True, phases=_lib.BWD_WEIGHTS_REDUCE, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(dx3, ref[0]) and torch.equal(outs3[0], ref[1]) and torch.equal(outs3[1], ref[2]) and torch.equal(outs3[2], ref[3])
 
 
 def test_full_size_properties_bf16():
