@@ -5,8 +5,9 @@ Workload (BASELINE.json configs[1]): the 56 SoWLinear layers of llama_60m (`--ar
 rank 50; 32 x (512->512), 16 x (512->1376), 8 x (1376->512), reference scripts/configs/llama_60m.json)
 at batch 128 x seq 256 = 32768 tokens per GPU, bf16.  One step = forward of all 56 layers in model
 order, backward of all 56 in reverse order (every layer has its own x / dY buffers, so nothing is
-re-read from cache that a real model would not have), and -- for N > 1 -- ONE RCCL all-reduce of the
-flat factor-gradient bucket.  Inputs are resident in HBM before the timed region.  The step is
+re-read from cache that a real model would not have; the token-slab partial sums of the weight gradients
+are reduced in one batched launch at the end of backward -- `--reduce layer` does it per layer, 3 % slower,
+bit-identical gradients), and -- for N > 1 -- ONE RCCL all-reduce of the flat factor-gradient bucket.  Inputs are resident in HBM before the timed region.  The step is
 captured in a HIP graph after warm-up (no host work in the timed region).
 
 Prints ONE JSON line.  `value` = tokens/s over all ranks (T * N / step time); `gflops` = the
@@ -53,6 +54,9 @@ def parse():
                     help="stack: the 56-layer SoWLinear hot path (headline); train: a full llama_60m training step "
                          "through the module-swap surface (prepare_sow, autograd, AdamW, accumulate), secondary figure")
     ap.add_argument("--accumulate-every", type=int, default=4, help="--mode train: SoW accumulation period in steps")
+    ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
+                    help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
+                         "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: weight-gradient kernels on a side stream (measured: -4 %%; only their small reduction on a side stream: -16 %% -- cross-stream edges of a HIP graph cost more than the 5-us kernel they hide)")
     return ap.parse_args()
@@ -61,11 +65,12 @@ def parse():
 class Stack:
     """The 56-layer SoWLinear stack with resident synthetic inputs."""
 
-    def __init__(self, shapes, T, r, dtype, device, acc, streams=1):
+    def __init__(self, shapes, T, r, dtype, device, acc, streams=1, reduce="layer"):
         from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
         self.streams = streams
+        self.deferred = ops.DeferredReduce() if reduce == "batch" else None
         self.side = torch.cuda.Stream(device=device) if streams > 1 else None
         kind = 2 if acc == "dense" else 0
         # per-layer workspaces (dh + slab partials): the split backward keeps them alive across two streams
@@ -106,7 +111,10 @@ class Stack:
             args = (self.dy[li], self.x[li], self.h[li], self.A[li].data, self.B[li].data, self.W[li], None, 1.0, False)
             kw = dict(out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0, workspace=self.ws[li],
                       dx=self.dx[self.shapes[li][0]][n % 4])
-            if self.side is None:
+            if self.deferred is not None:
+                ops.sow_backward(*args, phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL, **kw)
+                self.deferred.add(self.x[li], self.B[li].data, kw["out"], 0.0, self.ws[li], self.W[li], None)
+            elif self.side is None:
                 ops.sow_backward(*args, **kw)
             else:
                 ops.sow_backward(*args, phases=_lib.BWD_DATA, **kw)
@@ -115,12 +123,18 @@ class Stack:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev)
                     ops.sow_backward(*args, phases=_lib.BWD_WEIGHTS, **kw)
+        if self.deferred is not None:
+            self.deferred.run()
         if self.side is not None:
             main.wait_stream(self.side)
 
     def step(self):
         self.forward_all()
         self.backward_all()
+
+
+BWD_LABEL = {"layer": "backward: chain kernel + tn_partial + tn_reduce, x56 each",
+             "batch": "backward: chain kernel + tn_partial x56 each, one batched tn_reduce"}
 
 
 def algorithmic(shapes, T, r, es, acc):
@@ -268,7 +282,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    stack = Stack(shapes, T, args.rank, dtype, device, args.acc, args.streams)
+    stack = Stack(shapes, T, args.rank, dtype, device, args.acc, args.streams, args.reduce)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
 
@@ -320,7 +334,7 @@ def main():
         if rank == 0:
             it = max(3, min(args.steps, 10))
             groups["forward: chain kernel x56"] = time_region(stack.forward_all, it, stream)
-            groups["backward: chain kernel + tn_partial + tn_reduce, x56 each"] = time_region(stack.backward_all, it, stream)
+            groups[BWD_LABEL[args.reduce]] = time_region(stack.backward_all, it, stream)
 
     ms = elapsed / args.steps * 1e3
     flops, nbytes = algorithmic(shapes, T, args.rank, es, args.acc)
@@ -349,7 +363,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
-                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None, "streams": args.streams},
+                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None, "streams": args.streams, "weight_grad_reduce": args.reduce},
             "gflops": flops * world / (ms * 1e-3) / 1e9,
             "algorithmic_gbytes_per_step": nbytes / 1e9,
             "step_hbm_gbs": nbytes / (ms * 1e-3) / 1e9,

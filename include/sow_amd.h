@@ -99,6 +99,23 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
                     int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype,
                     void* workspace, size_t workspace_bytes, int phases, void* stream);
 
+/* Deferred, batched reduction of the weight gradients.  A training step calls sow_backward_ex(phases = SOW_BWD_DATA |
+ * SOW_BWD_WEIGHTS_PARTIAL) for every layer, each with its OWN workspace (the slab partials stay there), and sums all of
+ * them in ONE launch before the gradients are consumed (optimizer step / all-reduce): one launch instead of one 5-us
+ * launch per layer, same per-element summation order as SOW_BWD_WEIGHTS_REDUCE (bit-identical results).
+ *   sow_reduce_desc_bytes()    size of one opaque descriptor
+ *   sow_backward_reduce_desc() writes the descriptor of one layer to HOST memory `desc_out` and its block count to
+ *                              `blocks_out` (same shape / pointer arguments as the sow_backward_ex call it completes;
+ *                              SOW_ERR_UNSUPPORTED for r_live > 64, or r_live = 64 with dbias: those have no separate
+ *                              reduction -- use SOW_BWD_WEIGHTS)
+ *   sow_reduce_batch()         `descs`: n descriptors back to back in DEVICE memory; `starts`: n ints in device memory,
+ *                              starts[i] = sum of the block counts of layers < i; total_blocks = their total. */
+size_t sow_reduce_desc_bytes(void);
+int sow_backward_reduce_desc(void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out, int r_live, int r_acc,
+                             int acc_kind, float grad_beta, int dtype, void* workspace, size_t workspace_bytes, void* desc_out,
+                             int* blocks_out);
+int sow_reduce_batch(const void* descs, const int* starts, int n, int total_blocks, int dtype, void* stream);
+
 /* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
  * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call
  * sites: accumulate() sow.py:131-140 (W_acc += scale * A @ B, Q @ R), prepare.py:135, tt.py:213-237. */

@@ -31,6 +31,10 @@ SIGNATURES = {
                                                  c_void_p, c_size_t, c_void_p]),
     "sow_backward_ex": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                     c_void_p, c_size_t, c_int, c_void_p]),
+    "sow_reduce_desc_bytes": (c_size_t, []),
+    "sow_backward_reduce_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                         c_void_p, c_size_t, c_void_p, c_void_p]),
+    "sow_reduce_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sow_gemm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
                          c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "sow_qr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -2,6 +2,7 @@
 // Host-side dispatch only: picks the fused low-rank chain / skinny-TN kernels for r <= 64 and composes
 // the dense GEMM kernel for everything else.  No allocation, no synchronisation, no global state.
 #include "kernels.hpp"
+#include <cstring>
 #include <cstdlib>
 
 namespace sow {
@@ -138,6 +139,50 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   return w;
 }
 
+static char* ws_base(void* workspace) {
+  uintptr_t a = reinterpret_cast<uintptr_t>(workspace);
+  return reinterpret_cast<char*>((a + 255) & ~(uintptr_t)255);
+}
+
+// the reduction of the slab partials of one layer (shared by sow_backward_ex and the deferred, batched form)
+static ReduceParams make_reduce_params(const WsPlan& w, char* ws, void* dA, void* dB, void* dbias_ones, int d_in, int d_out,
+                                       int r_live, float grad_beta) {
+  ReduceParams rp{};
+  rp.njobs = 2, rp.ns = w.ns;
+  rp.job[0] = ReduceJob{(const float*)(ws + w.off_p0), dA, nullptr, (int64_t)r_live, d_in, (d_in + 63) / 64 * 64, r_live, 0, -1,
+                        1.f, grad_beta};
+  rp.job[1] = ReduceJob{(const float*)(ws + w.off_p1), dB, dbias_ones, (int64_t)d_out, d_out, (d_out + 63) / 64 * 64, r_live, 1,
+                        dbias_ones ? 63 : -1, 1.f /* h_save is already scaled */, grad_beta};
+  rp.blocks0 = (d_in + 3) / 4;
+  return rp;
+}
+
+size_t sow_reduce_desc_bytes(void) { return sizeof(ReduceParams); }
+
+int sow_backward_reduce_desc(void* dA, void* dB, void* dbias, int64_t T, int d_in, int d_out, int r_live, int r_acc,
+                             int acc_kind, float grad_beta, int dtype, void* workspace, size_t workspace_bytes, void* desc_out,
+                             int* blocks_out) {
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (T <= 0 || d_in <= 0 || d_out <= 0 || r_live <= 0) return SOW_ERR_SHAPE;
+  if (!dA || !dB || !workspace || !desc_out || !blocks_out) return SOW_ERR_NULL;
+  if (r_live > 64 || (dbias && r_live > 63)) return SOW_ERR_UNSUPPORTED;   // those paths have no separate reduction
+  if (acc_kind != SOW_ACC_LOWRANK) r_acc = 0;
+  const WsPlan w = plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype);
+  if (workspace_bytes < w.total + 255) return SOW_ERR_WORKSPACE;
+  const ReduceParams rp = make_reduce_params(w, ws_base(workspace), dA, dB, dbias, d_in, d_out, r_live, grad_beta);
+  memcpy(desc_out, &rp, sizeof(rp));
+  *blocks_out = (d_in + 3) / 4 + (d_out + 3) / 4;
+  return SOW_OK;
+}
+
+int sow_reduce_batch(const void* descs, const int* starts, int n, int total_blocks, int dtype, void* stream) {
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0 || total_blocks < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!descs || !starts) return SOW_ERR_NULL;
+  return launch_tn_reduce_batch((const ReduceParams*)descs, starts, n, total_blocks, dtype, (hipStream_t)stream);
+}
+
 size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0 || !ok_dtype(dtype)) return 0;
   const bool wide_acc = acc_kind == SOW_ACC_LOWRANK && r_acc > 64;
@@ -150,10 +195,6 @@ size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc
   return plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype).total + 256;
 }
 
-static char* ws_base(void* workspace) {
-  uintptr_t a = reinterpret_cast<uintptr_t>(workspace);
-  return reinterpret_cast<char*>((a + 255) & ~(uintptr_t)255);
-}
 
 int sow_forward(const void* x, const void* A, const void* B, const void* acc_down, const void* acc_up, const void* bias,
                 void* y, void* h_save, int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale,
@@ -360,12 +401,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       if (rc) return rc;
     }
     if (!do_reduce) return SOW_OK;
-    ReduceParams rp{};
-    rp.njobs = 2, rp.ns = w.ns;
-    rp.job[0] = ReduceJob{(const float*)(ws + w.off_p0), dA, nullptr, (int64_t)r_live, d_in, (d_in + 63) / 64 * 64, r_live, 0, -1,
-                          1.f, grad_beta};
-    rp.job[1] = ReduceJob{(const float*)(ws + w.off_p1), dB, ones_ok ? dbias : nullptr, (int64_t)d_out, d_out,
-                          (d_out + 63) / 64 * 64, r_live, 1, ones_ok ? 63 : -1, 1.f /* h_save is already scaled */, grad_beta};
+    const ReduceParams rp = make_reduce_params(w, ws, dA, dB, ones_ok ? dbias : nullptr, d_in, d_out, r_live, grad_beta);
     rc = launch_tn_reduce(rp, dtype, stream);
     if (rc) return rc;
     if (dbias && !ones_ok) {

@@ -77,6 +77,7 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
 size_t tn_partial_bytes(int ns, int D);
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
 int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);
+int launch_tn_reduce_batch(const ReduceParams* descs, const int* starts, int n, int total_blocks, int dtype, hipStream_t stream);
 // gemm.hip
 int launch_gemm(const void* A, int64_t lda, bool transA, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
                 const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream);

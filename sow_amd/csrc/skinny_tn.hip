@@ -685,8 +685,8 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnPara
 //   colsum[d] = sum_s partial[s][d][ones_col]
 // ---------------------------------------------------------------------------------------------
 
-template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(const ReduceParams p) {
-  int b = blockIdx.x, jid = 0;
+template <typename T> __device__ __forceinline__ void tn_reduce_body(const ReduceParams& p, int b) {
+  int jid = 0;
   if (p.njobs > 1 && b >= p.blocks0) {
     b -= p.blocks0;
     jid = 1;
@@ -742,6 +742,25 @@ template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(co
       *cs = from_f32<T>(v);
     }
   }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void tn_reduce_kernel(const ReduceParams p) {
+  tn_reduce_body<T>(p, (int)blockIdx.x);
+}
+
+// The reductions of many layers in one launch (deferred weight-gradient reduction): block -> layer by binary search in
+// the prefix sums of the per-layer block counts; same per-element summation order as the per-layer kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ReduceParams* __restrict__ descs, const int* __restrict__ starts,
+                                                              int n) {
+  int lo = 0, hi = n - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  tn_reduce_body<T>(descs[lo], b - starts[lo]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -820,6 +839,18 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
       hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
     }
   } else
+    return SOW_ERR_DTYPE;
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+int launch_tn_reduce_batch(const ReduceParams* descs, const int* starts, int n, int total_blocks, int dtype, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return SOW_OK;
+  if (dtype == SOW_BF16)
+    hipLaunchKernelGGL(tn_reduce_batch_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, descs, starts, n);
+  else if (dtype == SOW_F32)
+    hipLaunchKernelGGL(tn_reduce_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, descs, starts, n);
+  else
     return SOW_ERR_DTYPE;
   SOW_CHECK_LAUNCH();
   return SOW_OK;

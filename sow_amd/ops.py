@@ -171,6 +171,69 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
     return dx, dA, dB, dbias
 
 
+class DeferredReduce:
+    """The weight-gradient reductions of many layers in one launch (include/sow_amd.h: sow_reduce_batch).
+
+    Usage per step: `sow_backward(..., phases=BWD_DATA | BWD_WEIGHTS_PARTIAL, out=..., workspace=ws_i)` for every layer
+    (each layer its own workspace), then `run()` once before the gradients are consumed.  The descriptors are built on
+    the first step from `add()` calls and reused while the same buffers are passed again (static training buffers, HIP
+    graphs); `add()` with other pointers rebuilds them."""
+
+    def __init__(self):
+        self._keys, self._descs, self._blocks, self._dev, self._dt = [], [], [], None, None
+        self._d_descs = self._d_starts = None
+        self._total = 0
+        self._pos = 0
+
+    def add(self, x2, B, out, grad_beta, workspace, acc_down=None, acc_up=None):
+        """Register (or re-validate) the layer whose PARTIAL phase was just enqueued."""
+        lib = _lib.load()
+        dA, dB, dbias = out
+        T, d_in = x2.shape
+        r, d_out = B.shape
+        kind = acc_kind(acc_down, acc_up)
+        r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
+        key = (_ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(grad_beta), _dt(x2), _ptr(workspace))
+        i = self._pos
+        self._pos += 1
+        if i < len(self._keys) and self._keys[i] == key:
+            return
+        # new or changed layer: (re)build from here on
+        del self._keys[i:], self._descs[i:], self._blocks[i:]
+        self._d_descs = None
+        buf = ctypes.create_string_buffer(lib.sow_reduce_desc_bytes())
+        nb = ctypes.c_int(0)
+        _lib.check(lib.sow_backward_reduce_desc(_ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(grad_beta),
+                                                _dt(x2), _ptr(workspace), workspace.numel(), buf, ctypes.byref(nb)),
+                   "sow_backward_reduce_desc")
+        self._keys.append(key)
+        self._descs.append(buf.raw)
+        self._blocks.append(nb.value)
+        self._dev, self._dt = x2.device, _dt(x2)
+
+    def run(self):
+        """One launch for every layer added since the last run()."""
+        n = self._pos
+        self._pos = 0
+        if n == 0:
+            return
+        if n != len(self._keys):           # fewer layers than last step
+            del self._keys[n:], self._descs[n:], self._blocks[n:]
+            self._d_descs = None
+        if self._d_descs is None:
+            raw = b"".join(self._descs)
+            self._d_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self._dev)
+            starts, tot = [], 0
+            for b in self._blocks:
+                starts.append(tot)
+                tot += b
+            self._d_starts = torch.tensor(starts, dtype=torch.int32, device=self._dev)
+            self._total = tot
+        lib = _lib.load()
+        _lib.check(lib.sow_reduce_batch(_ptr(self._d_descs), _ptr(self._d_starts), n, self._total, self._dt, _stream(self._dev)),
+                   "sow_reduce_batch")
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
          bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -252,6 +252,39 @@ def test_backward_phases_split_equals_fused():
         assert torch.equal(dx3, ref[0]) and torch.equal(outs3[0], ref[1]) and torch.equal(outs3[1], ref[2]) and torch.equal(outs3[2], ref[3])
 
 
+def test_deferred_batched_reduce_is_bit_identical():
+    """sow_reduce_batch: DATA | WEIGHTS_PARTIAL per layer (own workspaces), one batched reduction at the end == the
+    per-layer WEIGHTS phase, bit for bit; second step reuses the descriptors; grad_beta = 1 accumulates."""
+    from sow_amd import _lib, ops
+    cases = [(4200, 512, 264, 50, True), (1000, 96, 160, 8, False), (5000, 264, 520, 34, True), (300, 128, 64, 62, True)]
+    for dtype in (torch.bfloat16, torch.float32):
+        g = lambda t: None if t is None else t.to(DEV, dtype)
+        layers = []
+        for i, (T, di, do, r, bias) in enumerate(cases):
+            x, dy, A, B, b, _, _ = _rand_case(T, di, do, r, None, bias, 500 + i)
+            x, dy, A, B, b = map(g, (x, dy, A, B, b))
+            y, h = ops.sow_forward(x, A, B, None, None, b, 0.5)
+            ref = ops.sow_backward(dy, x, h, A, B, None, None, 0.5, bias)
+            ws = torch.empty(ops.workspace_bytes(T, di, do, r, 0, 0, dtype) + 256, dtype=torch.uint8, device=DEV)
+            out = (torch.zeros_like(ref[1]), torch.zeros_like(ref[2]), torch.zeros_like(ref[3]) if bias else None)
+            layers.append((x, dy, h, A, B, bias, ref, ws, out, torch.empty_like(ref[0])))
+        dr = ops.DeferredReduce()
+        for step, beta in enumerate((0.0, 0.0, 1.0)):
+            for (x, dy, h, A, B, bias, ref, ws, out, dx) in layers:
+                ops.sow_backward(dy, x, h, A, B, None, None, 0.5, bias, out=out, grad_beta=beta, dx=dx, workspace=ws,
+                                 phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL)
+                dr.add(x, B, out, beta, ws)
+            dr.run()
+            torch.cuda.synchronize()
+            for (x, dy, h, A, B, bias, ref, ws, out, dx) in layers:
+                if beta == 0.0:
+                    assert torch.equal(dx, ref[0]) and torch.equal(out[0], ref[1]) and torch.equal(out[1], ref[2])
+                    assert (not bias) or torch.equal(out[2], ref[3])
+                else:   # accumulated onto the previous step's gradients
+                    assert rel_err(out[0].float().cpu(), 2 * ref[1].float().cpu()) < 1e-2
+                    assert rel_err(out[1].float().cpu(), 2 * ref[2].float().cpu()) < 1e-2
+
+
 def test_full_size_properties_bf16():
     """North-star size (T=32768, d=768, r=50, bf16): size-independent properties.
     y is linear in x; <dY, Y> = <dA, A> = <dB, B> (y is homogeneous of degree 1 in A and in B);
