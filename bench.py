@@ -54,6 +54,9 @@ def parse():
                     help="stack: the 56-layer SoWLinear hot path (headline); train: a full llama_60m training step "
                          "through the module-swap surface (prepare_sow, autograd, AdamW, accumulate), secondary figure")
     ap.add_argument("--accumulate-every", type=int, default=4, help="--mode train: SoW accumulation period in steps")
+    ap.add_argument("--fused-factors", action="store_true",
+                    help="--mode train, 1 GPU: factor group in a FactorBucket (gradients written straight into one flat buffer, "
+                         "one batched reduction, one fused AdamW kernel) instead of torch.optim.AdamW's second param group")
     ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
                     help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
                          "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
@@ -206,8 +209,17 @@ def train_mode(args, world, rank, device):
                 ids.add(id(wgt))
     model = model.to(device=device, dtype=torch.bfloat16)
     trainable = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
-    opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0},
-                             {"params": special, "lr": 1e-3, "weight_decay": 0.0}])
+    fused = args.fused_factors and world == 1
+    if fused:
+        from sow_amd.dp import FactorBucket
+        from sow_amd.optimizer import FactorAdamW
+        bucket = FactorBucket(special)
+        bucket.attach(model)
+        fopt = FactorAdamW(bucket, lr=1e-3, weight_decay=0.0)
+        opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0}])
+    else:
+        opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0},
+                                 {"params": special, "lr": 1e-3, "weight_decay": 0.0}])
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], output_device=device.index,
                                                           broadcast_buffers=False)
@@ -221,10 +233,19 @@ def train_mode(args, world, rank, device):
         loss.backward()
         step_no[0] += 1
         if step_no[0] % args.accumulate_every == 0:      # simple_train.py:618-626 (GA = 1)
+            if fused:
+                bucket.finalize()
             accumulate(model.module if world > 1 else model)
-            reset_optimizer(opt, group_id=1)
+            if fused:
+                bucket.rebind()
+                fopt.reset_state()
+            else:
+                reset_optimizer(opt, group_id=1)
         opt.step()
         opt.zero_grad()
+        if fused:
+            fopt.step()
+            bucket.zero_grad()
         return loss
 
     for _ in range(max(args.warmup, 1)):
@@ -252,7 +273,7 @@ def train_mode(args, world, rank, device):
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "llama_60m (HF LlamaForCausalLM from config) + prepare_sow rank 50, batch 128 x seq 256, "
                                    f"AdamW 2 groups, accumulate every {args.accumulate_every} steps",
-                       "parallelism": f"ddp{world}", "final_loss": float(loss.detach())}}))
+                       "parallelism": f"ddp{world}", "fused_factors": bool(fused), "final_loss": float(loss.detach())}}))
 
 
 def main():

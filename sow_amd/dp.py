@@ -35,6 +35,43 @@ def factor_parameters(model: nn.Module) -> List[nn.Parameter]:
     return out
 
 
+class _GradSink:
+    """Per-layer hook used by SoWLinear's autograd backward after FactorBucket.attach(): runs the data gradient and the
+    token-slab partial sums of the weight gradients (own persistent workspace), accumulating into the layer's views of
+    the flat gradient buffer, and registers the layer with the bucket's deferred reduction."""
+
+    def __init__(self, bucket, pA, pB):
+        self.bucket, self.pA, self.pB = bucket, pA, pB
+        self.ws = None
+        self.pending = False
+
+    def usable(self, A, B) -> bool:
+        # n_iter == 1 layers only (A, B ARE the bucket's parameters), gradients bound to the flat buffer, r <= 64
+        pA, pB = self.pA, self.pB
+        return (A.data_ptr() == pA.data_ptr() and B.data_ptr() == pB.data_ptr() and B.shape[0] <= 64
+                and pA.grad is not None and pB.grad is not None
+                and pA.grad.data_ptr() == self.bucket.grad_ptr(pA) and pB.grad.data_ptr() == self.bucket.grad_ptr(pB))
+
+    def backward(self, dy2, x2, h, A, B, acc_down, acc_up, scale):
+        from . import _lib, ops
+        if self.pending:             # second backward through this layer before finalize(): its partials are still needed
+            self.bucket.finalize()
+        T, d_in = x2.shape
+        r, d_out = B.shape
+        kind = ops.acc_kind(acc_down, acc_up)
+        r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
+        need = ops.workspace_bytes(T, d_in, d_out, r, r_acc, kind, x2.dtype) + 256
+        if self.ws is None or self.ws.numel() < need or self.ws.device != x2.device:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=x2.device)
+        out = (self.pA.grad, self.pB.grad, None)
+        dx, _, _, _ = ops.sow_backward(dy2, x2, h, A, B, acc_down, acc_up, scale, False, out=out, grad_beta=1.0,
+                                       phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL, workspace=self.ws)
+        self.bucket._reducer.add(x2, B, out, 1.0, self.ws, acc_down, acc_up)
+        self.bucket._sinks_pending.append(self)
+        self.pending = True
+        return dx
+
+
 class FactorBucket:
     """Re-homes the factor parameters (and their .grad) as views into two flat buffers."""
 
@@ -61,6 +98,40 @@ class FactorBucket:
             p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
         self._work = None
         self._comm_stream: Optional[torch.cuda.Stream] = None
+        self._reducer = None
+        self._sinks_pending: list = []
+        self._off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+
+    # ------------------------------------------------------------------ deferred weight-gradient reduction
+    def grad_ptr(self, p) -> int:
+        return self.flat_grad.data_ptr() + self._off_of[id(p)] * self.flat_grad.element_size()
+
+    def attach(self, model: nn.Module) -> int:
+        """Let the SoWLinear layers of `model` (n_iter = 1, no bias) write their weight gradients straight into the
+        flat buffer and defer the final reduction to finalize(): one launch per step instead of one per layer, and no
+        per-parameter AccumulateGrad.  Gradients ACCUMULATE (zero_grad() between steps); call finalize() after
+        backward, before the gradients are read (all_reduce_async() and FactorAdamW.step() do).  Returns the number of
+        layers attached; layers with a bias or n_iter > 1 keep the ordinary autograd path."""
+        from . import ops
+        if self._reducer is None:
+            self._reducer = ops.DeferredReduce()
+        mine = {id(p) for p in self.params}
+        n = 0
+        for _, m in model.named_modules():
+            if isinstance(m, SoWLinear) and m.n_iter == 1 and m.bias is None:
+                pA, pB = m.downscale_weights._parameters["0"], m.upscale_weights._parameters["0"]
+                if id(pA) in mine and id(pB) in mine:
+                    m._grad_sink = _GradSink(self, pA, pB)
+                    n += 1
+        return n
+
+    def finalize(self) -> None:
+        """Sum the pending slab partials of every attached layer (no-op when nothing is pending)."""
+        if self._reducer is not None and self._sinks_pending:
+            self._reducer.run()
+            for s in self._sinks_pending:
+                s.pending = False
+            self._sinks_pending.clear()
 
     def rebind(self) -> None:
         """Call after SoWLinear.accumulate(): `from_weights` rebinds .data to fresh tensors
@@ -87,6 +158,7 @@ class FactorBucket:
     def all_reduce_async(self, group=None, average: bool = True) -> None:
         """One sum all-reduce of the whole factor-gradient bucket (RCCL over xGMI on GPUs, gloo on CPU
         in the tests).  On GPU it runs on a side stream ordered after the current stream."""
+        self.finalize()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
         op = dist.ReduceOp.SUM

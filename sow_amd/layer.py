@@ -39,7 +39,7 @@ class _SoWFunction(torch.autograd.Function):
     """y = acc_term + scale * (x @ A) @ B + bias through sow_forward / sow_backward (include/sow_amd.h)."""
 
     @staticmethod
-    def forward(ctx, x, A, B, acc_down, acc_up, bias, scale):
+    def forward(ctx, x, A, B, acc_down, acc_up, bias, scale, sink=None):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         y, h = ops.sow_forward(x2, A, B, acc_down, acc_up, bias, scale)
@@ -47,14 +47,22 @@ class _SoWFunction(torch.autograd.Function):
         ctx.scale = scale
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
+        ctx.sink = sink
         return y.reshape(*lead, B.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
         x2, h, A, B, acc_down, acc_up = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
+        sink = ctx.sink
+        if sink is not None and not ctx.has_bias and x2.shape[0] > 0 and sink.usable(A, B):
+            # FactorBucket.attach(): the weight gradients accumulate straight into the flat gradient buffer (p.grad is a
+            # view of it), so autograd gets None for A and B; their slab-partial sums are reduced for all layers in one
+            # launch by FactorBucket.finalize() (sow_reduce_batch).
+            dx = sink.backward(dy2, x2, h, A, B, acc_down, acc_up, ctx.scale)
+            return dx.reshape(ctx.x_shape), None, None, None, None, None, None, None
         dx, dA, dB, dbias = ops.sow_backward(dy2, x2, h, A, B, acc_down, acc_up, ctx.scale, ctx.has_bias)
-        return dx.reshape(ctx.x_shape), dA, dB, None, None, dbias, None
+        return dx.reshape(ctx.x_shape), dA, dB, None, None, dbias, None, None
 
 
 class SoWLinear(nn.Module):
@@ -119,7 +127,8 @@ class SoWLinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """sow.py:107-126 in one fused call: accumulator term (not scaled) + scale * (x A) B + bias."""
         A, B = self._cat_factors()
-        return _SoWFunction.apply(x, A, B, self.acc_downweight, self.acc_upweight, self.bias, float(self.scale))
+        return _SoWFunction.apply(x, A, B, self.acc_downweight, self.acc_upweight, self.bias, float(self.scale),
+                                  getattr(self, "_grad_sink", None))
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -141,6 +141,7 @@ class FactorAdamW:
         self.step_count = 0
 
     def step(self, grad_scale: float = 1.0):
+        self.bucket.finalize()   # pending deferred weight-gradient reductions (FactorBucket.attach)
         self.step_count += 1
         ops.adamw_flat_(self.bucket.flat_param, self.bucket.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
                         betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, step=self.step_count,

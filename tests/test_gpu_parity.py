@@ -285,6 +285,53 @@ def test_deferred_batched_reduce_is_bit_identical():
                     assert rel_err(out[1].float().cpu(), 2 * ref[2].float().cpu()) < 1e-2
 
 
+def test_bucket_attach_gradients_equal_autograd_path():
+    """FactorBucket.attach(): SoWLinear's backward accumulates straight into the flat gradient buffer and the reductions
+    of all layers run in one launch at finalize() -- same gradients, bit for bit, as the ordinary autograd path; a second
+    backward before finalize() (gradient accumulation) adds up."""
+    import copy
+    from sow_amd import SoWLinear
+    from sow_amd.dp import FactorBucket, factor_parameters
+    from sow_amd.optimizer import FactorAdamW
+    torch.manual_seed(3)
+    dims = [(96, 160, 8, False), (160, 64, 16, False), (64, 200, 8, True), (200, 72, 34, False)]
+    for dtype in (torch.bfloat16, torch.float32):
+        ref = torch.nn.ModuleList([SoWLinear(i, o, bias=b, rank=r, init_method="normal", device=DEV, dtype=dtype) for i, o, r, b in dims])
+        for m in ref:
+            torch.nn.init.normal_(m.upscale_weights[0], std=0.05)
+        net = copy.deepcopy(ref)
+        bucket = FactorBucket(factor_parameters(net))
+        assert bucket.attach(net) == 3          # the layer with a bias keeps the autograd path
+        x = torch.randn(700, 96, device=DEV, dtype=dtype)
+
+        def run(mods, xin):
+            h = xin
+            for m in mods:
+                h = torch.tanh(m(h))
+            return h.float().square().mean()
+
+        run(ref, x).backward()
+        bucket.zero_grad()
+        run(net, x).backward()
+        bucket.finalize()
+        torch.cuda.synchronize()
+        for a, b in zip(ref, net):
+            assert torch.equal(a.downscale_weights[0].grad, b.downscale_weights[0].grad)
+            assert torch.equal(a.upscale_weights[0].grad, b.upscale_weights[0].grad)
+            if a.bias is not None:
+                assert torch.equal(a.bias.grad, b.bias.grad)
+        # accumulation: a second backward without zero_grad; FactorAdamW.step finalizes by itself
+        run(ref, x).backward()
+        run(net, x).backward()
+        run(ref, x).backward()
+        run(net, x).backward()      # partials of the previous backward still pending: the sink finalizes them first
+        opt = FactorAdamW(bucket, lr=1e-3)
+        opt.step()
+        torch.cuda.synchronize()
+        for a, b in zip(ref, net):
+            assert rel_err(b.downscale_weights[0].grad.float().cpu(), a.downscale_weights[0].grad.float().cpu()) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
 def test_full_size_properties_bf16():
     """North-star size (T=32768, d=768, r=50, bf16): size-independent properties.
     y is linear in x; <dY, Y> = <dA, A> = <dB, B> (y is homogeneous of degree 1 in A and in B);
