@@ -10,7 +10,8 @@
  *
  * Conventions:
  *   - every function returns int: 0 ok, <0 argument error (SOW_ERR_*), >0 hipError_t;
- *   - nothing here allocates or frees device memory or synchronises the device;
+ *   - nothing here allocates or frees device memory or synchronises the device; no mutable global state except
+ *     the kernel-selection switches (sow_set_switch), which production code leaves alone;
  *     the caller passes a workspace sized by the matching *_workspace_bytes query;
  *   - all tensors are dense row-major device buffers, 16-byte aligned for the
  *     fast paths (unaligned / odd shapes take slower element-wise paths);
@@ -50,6 +51,16 @@ extern "C" {
 
 int sow_version(void);
 const char* sow_error_string(int code);
+
+/* Kernel-selection switches -- for A/B measurements and for the tests that pin every kernel variant; production code
+ * never touches them.  They are the library's ONLY process-wide state: a table of atomics initialised from the
+ * environment (SOW_AMD_<NAME>) once, at first use; no launch path calls getenv.  Names: FORCE_CHAIN_V1, NO_SHORT_SPLIT,
+ * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED (value 1 = on, -1 / 0 = off) and GEMM3S, GEMM3
+ * (1 = force, 0 = forbid, -1 = automatic).  sow_set_switch returns SOW_ERR_UNSUPPORTED for an unknown name;
+ * sow_get_switch returns the value (-1 / 0 / 1).  Changing a switch while other threads launch is safe (atomic) but
+ * the launches in flight may see either value. */
+int sow_set_switch(const char* name, int value);
+int sow_get_switch(const char* name);
 
 /* Bytes of workspace needed by sow_forward / sow_backward for this shape. */
 size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);

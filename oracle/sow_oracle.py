@@ -496,6 +496,76 @@ def tt_round(cores: List[Tensor], ranks: List[int], in_shape, out_shape, new_ran
     return cores, ranks
 
 
+def _tt_meta(cores: Sequence[Tensor]):
+    """ranks, in_shape, out_shape as TensorTrain.from_cores derives them from the core shapes."""
+    ranks = [c.shape[0] for c in cores] + [cores[-1].shape[-1]]
+    return ranks, [c.shape[1] for c in cores], [c.shape[2] for c in cores]
+
+
+def _tt_round(cores, new_ranks):
+    ranks, ins, outs = _tt_meta(cores)
+    return tt_round([c.clone() for c in cores], ranks, ins, outs, list(new_ranks))[0]
+
+
+def _tt_sub(a, b):
+    """tt.py:424-426: a + (-1) * b."""
+    return tt_add(a, tt_scale(b, -1))
+
+
+def tt_sqrt(cores: Sequence[Tensor], threshold: float = 1e-3, max_iter: int = 4) -> List[Tensor]:
+    """TensorTrain.sqrt (tt.py:312-341): coupled Newton iteration on the train scaled by 4^-k, where
+    k = floor(log_4(prod(ranks) * max|last core|)); every product is rounded back to the starting ranks.  `add_` is NOT
+    in place in the reference (it returns a new train, :343-379), so `C.add_(-3)` leaves C untouched."""
+    ranks, _, _ = _tt_meta(cores)
+    max_value = math.prod(ranks) * float(cores[-1].abs().max())
+    k = math.floor(math.log(max_value) / math.log(4))
+    A = tt_scale(cores, 1 / (4 ** k))
+    C = tt_add_constant(A, ranks, -1)
+    while max_iter > 0 and tt_inner(_tt_sub(A, C), _tt_sub(A, C), mode="full") > threshold:
+        B = _tt_round(_tt_sub(A, tt_scale(tt_mul(A, C), 1 / 2)), ranks)
+        D = tt_mul(tt_scale(_tt_round(tt_mul(C, C), ranks), 1 / 4), tt_add_constant(C, _tt_meta(C)[0], -3))
+        D = _tt_round(D, ranks)
+        max_iter -= 1
+        A, C = B, D
+    return tt_scale(A, 2 ** k)
+
+
+def tt_sqrtinv(cores: Sequence[Tensor], threshold: Optional[float] = 1e-8, max_iter: int = 4) -> List[Tensor]:
+    """TensorTrain.sqrtinv (tt.py:279-310): Newton iteration for x^-1/2 with every product rounded to the maximal ranks
+    [1, i_k * o_k, ..., 1]; scaling k from max|core| ** (order // 2) * prod(ranks)."""
+    ranks, ins, outs = _tt_meta(cores)
+    order = len(cores)
+    max_value = float(max(float(c.abs().max()) for c in cores))
+    max_value = math.prod(ranks) * (max_value ** (order // 2))
+    k = math.floor(math.log(max_value) / math.log(4))
+    c, revc = 1 / (4 ** k), 2 ** k
+    A = tt_scale(cores, c)
+    max_ranks = [1] + [i * o for i, o in zip(ins, outs)] + [1]
+    while max_iter > 0:
+        inner = tt_mul(cores, _tt_round(tt_mul(A, A), max_ranks))
+        B = _tt_round(tt_scale(tt_add_constant(inner, _tt_meta(inner)[0], -3), -1 / 2), max_ranks)
+        C = _tt_round(tt_mul(A, B), max_ranks)
+        if threshold:
+            diff = _tt_sub(C, A)
+            if abs(tt_inner(diff, diff, mode="full")) < threshold:
+                return tt_scale(C, revc)
+        A = C
+        max_iter -= 1
+    return tt_scale(A, revc)
+
+
+def tt_reciprocal(cores: Sequence[Tensor]) -> List[Tensor]:
+    """TensorTrain.reciprocal (tt.py:480-494): first and last cores copied, every [:, i, o, :] slice of the middle cores
+    replaced by its matrix inverse."""
+    out = []
+    for idx, c in enumerate(cores):
+        if idx in (0, len(cores) - 1):
+            out.append(c.clone())
+        else:
+            out.append(torch.linalg.inv(c.permute(1, 2, 0, 3)).permute(2, 0, 1, 3).contiguous())
+    return out
+
+
 # --------------------------------------------------------------------------
 # L1' TT optimizers  (tn_gradient/optimizer/ttadam.py, ttsgd.py)
 # --------------------------------------------------------------------------

@@ -22,6 +22,8 @@ BWD_DATA, BWD_WEIGHTS, BWD_WEIGHTS_PARTIAL, BWD_WEIGHTS_REDUCE = 1, 2, 4, 8
 SIGNATURES = {
     "sow_version": (c_int, []),
     "sow_error_string": (c_char_p, [c_int]),
+    "sow_set_switch": (c_int, [c_char_p, c_int]),
+    "sow_get_switch": (c_int, [c_char_p]),
     "sow_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sow_forward_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int, c_int, c_int]),
     "sow_h_save_elems": (c_size_t, [c_int64, c_int]),
@@ -81,3 +83,25 @@ def check(code: int, what: str = "") -> None:
     if code != 0:
         msg = load().sow_error_string(code).decode()
         raise SowLibraryError(f"libsow_amd {what} failed with code {code}: {msg}")
+
+
+class switch:
+    """Context manager over sow_set_switch for tests and A/B tools: `with _lib.switch(NO_FUSED_H=1): ...` sets the
+    kernel-selection switch explicitly (no environment, no getenv on the launch path) and restores it afterwards."""
+
+    def __init__(self, **values):
+        self.values = values
+        self.old = {}
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.values.items():
+            self.old[k] = lib.sow_get_switch(k.encode())
+            check(lib.sow_set_switch(k.encode(), int(v)), f"sow_set_switch({k})")
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.old.items():
+            lib.sow_set_switch(k.encode(), v)
+        return False

@@ -1,8 +1,10 @@
 // extern "C" entry points of libsow_amd.so (declared in include/sow_amd.h).
 // Host-side dispatch only: picks the fused low-rank chain / skinny-TN kernels for r <= 64 and composes
-// the dense GEMM kernel for everything else.  No allocation, no synchronisation, no global state.
+// the dense GEMM kernel for everything else.  No allocation, no synchronisation; the only process-wide state is the
+// table of kernel-selection switches below (atomics, read from the environment once).
 #include "kernels.hpp"
 #include <cstring>
+#include <cstdio>
 #include <cstdlib>
 
 namespace sow {
@@ -22,6 +24,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
     if (beta != 0.f) v += beta * to_f32(out[c]);
     out[c] = from_f32<T>(v);
   }
+}
+}  // namespace sow
+
+// ---- kernel-selection switches (common.hpp: enum Switch) ----------------------------------------------
+namespace sow {
+static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
+                                                   "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED"};
+static std::atomic<int> g_switch[SW_COUNT];
+static std::once_flag g_switch_once;
+static void switches_from_env() {
+  for (int i = 0; i < SW_COUNT; ++i) {
+    char name[64];
+    snprintf(name, sizeof name, "SOW_AMD_%s", kSwitchNames[i]);
+    const char* v = getenv(name);
+    // tri-state switches take "0" / "1"; for the boolean ones any value (even empty) means on, as before
+    const bool tri = i == SW_GEMM3S || i == SW_GEMM3;
+    g_switch[i].store(!v ? -1 : (tri ? (v[0] != '0') : 1), std::memory_order_relaxed);
+  }
+}
+int sw(int which) {
+  std::call_once(g_switch_once, switches_from_env);
+  return g_switch[which].load(std::memory_order_relaxed);
 }
 }  // namespace sow
 
@@ -52,8 +76,7 @@ static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* 
   const int ntb = ceil_div(p.M, 64);
   const bool f32 = dtype == SOW_F32;
   if (!hpartial || !p.Hsave || ntb > SHORT_NTB || !(f32 ? chain2f_supported(p, dtype) : chain2_supported(p, dtype)) ||
-      getenv("SOW_AMD_FORCE_CHAIN_V1") ||
-      getenv("SOW_AMD_NO_SHORT_SPLIT"))
+      sw_on(SW_FORCE_CHAIN_V1) || sw_on(SW_NO_SHORT_SPLIT))
     return SOW_ERR_UNSUPPORTED;
   const int want = short_want(ntb);
   const int nst = (p.D1 + 63) / 64, nsl = (p.D2 + 63) / 64;
@@ -93,7 +116,25 @@ static int gemm_auto(const void* A, int64_t lda, const void* B, int64_t ldb, boo
 
 extern "C" {
 
-int sow_version(void) { return 100; }
+int sow_version(void) { return 110; }
+
+int sow_set_switch(const char* name, int value) {
+  if (!name) return SOW_ERR_NULL;
+  (void)sw(0);   // make sure the environment has been read first
+  for (int i = 0; i < SW_COUNT; ++i)
+    if (!strcmp(name, kSwitchNames[i])) {
+      g_switch[i].store(value < 0 ? -1 : (value != 0), std::memory_order_relaxed);
+      return SOW_OK;
+    }
+  return SOW_ERR_UNSUPPORTED;
+}
+
+int sow_get_switch(const char* name) {
+  if (!name) return SOW_ERR_NULL;
+  for (int i = 0; i < SW_COUNT; ++i)
+    if (!strcmp(name, kSwitchNames[i])) return sw(i);
+  return SOW_ERR_UNSUPPORTED;
+}
 
 const char* sow_error_string(int code) {
   switch (code) {

@@ -412,11 +412,11 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream) {
   if (!p.X || !p.Y) return SOW_ERR_NULL;
   if (p.ra != 0 || p.rb <= 0 || p.rb > CH_RP) return SOW_ERR_SHAPE;
   if (!p.F1b || !p.F2b) return SOW_ERR_NULL;
-  if (chain2_supported(p, dtype) && !getenv("SOW_AMD_FORCE_CHAIN_V1")) {
+  if (chain2_supported(p, dtype) && !sw_on(SW_FORCE_CHAIN_V1)) {
     const int rc = launch_chain2(p, bwd, stream);
     if (rc != SOW_ERR_ALIGN) return rc;  // factor alignment not met: fall through to the generic kernel
   }
-  if (chain2f_supported(p, dtype) && !getenv("SOW_AMD_FORCE_CHAIN_V1")) {
+  if (chain2f_supported(p, dtype) && !sw_on(SW_FORCE_CHAIN_V1)) {
     const int rc = launch_chain2f(p, bwd, stream);
     if (rc != SOW_ERR_ALIGN) return rc;
   }

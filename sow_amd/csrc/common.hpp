@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/sow_amd.h"
@@ -101,15 +102,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Raise a kernel's dynamic-LDS limit exactly once per process (thread-safe: forward runs on the caller's thread,
-// backward on the autograd thread).  The kernel expression goes last because template-ids contain commas.
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; thread-safe: forward runs on the
+// caller's thread, backward on the autograd thread -- two threads racing here both set the same value).  The kernel
+// expression goes last because template-ids contain commas.
 #define SOW_SET_MAX_LDS_ONCE(bytes, ...)                                                                            \
   do {                                                                                                              \
-    static std::once_flag once__;                                                                                   \
-    std::call_once(once__, [] {                                                                                     \
+    static std::atomic<uint64_t> done__{0};                                                                         \
+    int dev__ = 0;                                                                                                  \
+    (void)hipGetDevice(&dev__);                                                                                     \
+    const uint64_t bit__ = 1ull << (dev__ & 63);                                                                    \
+    if (!(done__.load(std::memory_order_acquire) & bit__)) {                                                        \
       (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));    \
-    });                                                                                                             \
+      done__.fetch_or(bit__, std::memory_order_release);                                                            \
+    }                                                                                                               \
   } while (0)
+
+// Kernel-selection switches (A/B measurements and the tests that pin every kernel variant).  Read from the
+// environment ONCE, when the library is first used (SOW_AMD_<NAME>), and changed afterwards only through
+// sow_set_switch() (include/sow_amd.h); launches read an atomic, never getenv.  -1 = unset (automatic choice).
+enum Switch : int {
+  SW_FORCE_CHAIN_V1 = 0,  // generic chain kernels instead of the streaming ones
+  SW_NO_SHORT_SPLIT,      // no K / column split of the chain for short inputs
+  SW_NO_FUSED_H,          // dense-accumulator layer as H-only chain + K-extended GEMM (no gemm2h)
+  SW_FORCE_GEMM_V1,       // generic GEMM kernel everywhere
+  SW_TN_NARROW,           // one column group per skinny-TN workgroup
+  SW_NO_GEMM3S,           // never the 128x128-tile streaming GEMM
+  SW_GEMM3S,              // 1 / 0: force / forbid gemm3s
+  SW_GEMM3,               // 1 / 0: force / forbid gemm3
+  SW_NO_GROUPED,          // grouped (multi-layer) entry points launch layer by layer
+  SW_COUNT
+};
+int sw(int which);
+inline bool sw_on(int which) { return sw(which) > 0; }
 
 #define SOW_CHECK_LAUNCH()                     \
   do {                                         \

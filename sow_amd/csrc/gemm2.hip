@@ -244,9 +244,9 @@ bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
   // picks the kernel); below ~96 of those, or with a short K, the generic kernel is as good
   if (N < 64 || K < 32) return false;
   if ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160 &&
-      ((int64_t)ceil_div(M, 128) * ceil_div(N, 128) < 96 || K < 512 || getenv("SOW_AMD_NO_GEMM3S")))
+      ((int64_t)ceil_div(M, 128) * ceil_div(N, 128) < 96 || K < 512 || sw_on(SW_NO_GEMM3S)))
     return false;
-  if (getenv("SOW_AMD_FORCE_GEMM_V1")) return false;      // A/B switch, as SOW_AMD_FORCE_CHAIN_V1
+  if (sw_on(SW_FORCE_GEMM_V1)) return false;      // A/B switch, as SOW_AMD_FORCE_CHAIN_V1
   if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return false;
   if (!g2_al16(A) || !g2_al16(B) || !g2_al16(C) || (bias && !g2_al16(bias))) return false;
   if (A2) {
@@ -268,13 +268,13 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   const int64_t tiles = (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
-  const char* gs = getenv("SOW_AMD_GEMM3S");
-  if (gs ? (gs[0] != '0') : ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160))
+  const int gs = sw(SW_GEMM3S);
+  if (gs >= 0 ? gs != 0 : ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160))
     return launch_gemm3s(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
   // long K: the one-wave-per-SIMD kernel (gemm3.hip) is 7-19 % faster from K ~ 2048 on (4096^3: 1.05 vs 0.90-0.96 PF);
   // at the llama_60m widths (K <= 1376) the two are level or this one is ahead.  SOW_AMD_GEMM3=1 / =0 force either.
-  const char* g3 = getenv("SOW_AMD_GEMM3");
-  if (g3 ? (g3[0] != '0') : (K >= 2048))
+  const int g3 = sw(SW_GEMM3);
+  if (g3 >= 0 ? g3 != 0 : (K >= 2048))
     return launch_gemm3(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
   if (nt) {
     SOW_SET_MAX_LDS_ONCE(G2_LDS, gemm2_kernel<true>);

@@ -388,7 +388,7 @@ bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bo
                       const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,
                       int N, int K, int r, int dtype) {
   if (dtype != SOW_BF16 || !X || !W || !F || !G || !C || !H) return false;
-  if (getenv("SOW_AMD_NO_FUSED_H") || getenv("SOW_AMD_FORCE_GEMM_V1")) return false;   // A/B switches
+  if (sw_on(SW_NO_FUSED_H) || sw_on(SW_FORCE_GEMM_V1)) return false;   // A/B switches
   // r >= 4: a 16-byte piece spans at most two 2r-byte rows, so only the LAST row has pieces crossing the end of the buffer
   if (r < 4 || r > 64 || (r & 1)) return false;
   if (N < 64 || K < 128) return false;

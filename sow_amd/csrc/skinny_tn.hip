@@ -811,7 +811,7 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
       dma = dma && J.D % 8 == 0 && J.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
     }
-    if (dma && !getenv("SOW_AMD_TN_NARROW")) {
+    if (dma && !sw_on(SW_TN_NARROW)) {
       constexpr int LDS = TNW_WAVES * TNW_DEPTH * TNW_STAGE_BYTES;  // 144 KiB (rings; reused by the cross-wave sum)
       SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
       int blocks2 = 0;   // two 64-column groups per block

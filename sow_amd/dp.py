@@ -165,7 +165,7 @@ class FactorBucket:
         if self.flat_grad.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=self.flat_grad.device)
-            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
             with torch.cuda.stream(self._comm_stream):
                 self._work = dist.all_reduce(self.flat_grad, op=op, group=group, async_op=True)
         else:
@@ -180,7 +180,7 @@ class FactorBucket:
             return 1.0
         self._work.wait()
         if self.flat_grad.is_cuda and self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
         self._work = None
         return 1.0 / dist.get_world_size(self._group) if self._average else 1.0
 

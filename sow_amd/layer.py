@@ -41,7 +41,14 @@ class _SoWFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, A, B, acc_down, acc_up, bias, scale, sink=None):
         lead = x.shape[:-1]
-        x2 = x.reshape(-1, x.shape[-1])
+        # the kernels take dense row-major buffers: a strided view (x = big[..., :d], seq[:, 0, :], W.t()) is packed ONCE
+        # here so that forward and backward read the same rows (backward passes raw pointers of the saved tensors)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        A, B = A.contiguous(), B.contiguous()
+        if acc_down is not None and acc_down.numel():
+            acc_down = acc_down.contiguous()
+        if acc_up is not None and acc_up.numel():
+            acc_up = acc_up.contiguous()
         y, h = ops.sow_forward(x2, A, B, acc_down, acc_up, bias, scale)
         ctx.save_for_backward(x2, h, A, B, acc_down, acc_up)
         ctx.scale = scale
@@ -172,8 +179,8 @@ class SoWLinear(nn.Module):
                                          self.acc_downweight.dtype)
                 q, _ = ops.qr_thin(w, self.rank, need_r=False)
                 new_down[i] = q.contiguous()
-            else:
-                nn.init.normal_(new_down[i], std=0.02)
+            else:   # plain Gaussian re-init (sow.py:174), through the same draw hook as the QR branch
+                new_down[i] = self._fresh_gaussian(tuple(new_down[i].shape), new_down[i].device, new_down[i].dtype)
         self.downscale_weights.from_weights(new_down)
         self.upscale_weights.from_weights(new_up)
 

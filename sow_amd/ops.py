@@ -54,6 +54,18 @@ def _stream(device: Optional[torch.device] = None) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _launch(dev: torch.device, what: str, fn, *args) -> None:
+    """Call a C-ABI launcher with the tensors' device current (the kernels run on the HIP device that is current on the
+    calling thread; the stream argument is that device's current torch stream).  One process per GPU never takes the
+    slow branch; a process that touches several GPUs gets the right device instead of an invalid-handle error."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx == torch.cuda.current_device():
+        _lib.check(fn(*args, _stream(dev)), what)
+    else:
+        with torch.cuda.device(idx):
+            _lib.check(fn(*args, _stream(dev)), what)
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -122,9 +134,8 @@ def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, ac
     # the forward touches a workspace only for some shapes (include/sow_amd.h: sow_forward_workspace_bytes)
     nws = _forward_workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt)
     ws = _ws(nws, dev) if nws else None
-    _lib.check(lib.sow_forward(_ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y), _ptr(h),
-                               T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), 0 if ws is None else ws.numel(),
-                               _stream(dev)), "sow_forward")
+    _launch(dev, "sow_forward", lib.sow_forward, _ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y),
+            _ptr(h), T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), 0 if ws is None else ws.numel())
     return y, h
 
 
@@ -163,11 +174,10 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
     ws = _ws(nws, dev) if workspace is None else workspace
     if ws.numel() < nws:
         raise ValueError("sow_amd: workspace too small")
-    _lib.check(lib.sow_backward_ex(_ptr(dy2), _ptr(x2), _ptr(h), _ptr(A), _ptr(B),
-                                   _ptr(acc_down) if kind != _lib.ACC_NONE else None,
-                                   _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
-                                   _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale),
-                                   float(grad_beta), dt, _ptr(ws), ws.numel(), int(phases), _stream(dev)), "sow_backward")
+    _launch(dev, "sow_backward", lib.sow_backward_ex, _ptr(dy2), _ptr(x2), _ptr(h), _ptr(A), _ptr(B),
+            _ptr(acc_down) if kind != _lib.ACC_NONE else None, _ptr(acc_up) if kind == _lib.ACC_LOWRANK else None,
+            _ptr(dx), _ptr(dA), _ptr(dB), _ptr(dbias), T, d_in, d_out, r, r_acc, kind, float(scale), float(grad_beta), dt,
+            _ptr(ws), ws.numel(), int(phases))
     return dx, dA, dB, dbias
 
 
@@ -230,8 +240,8 @@ class DeferredReduce:
             self._d_starts = torch.tensor(starts, dtype=torch.int32, device=self._dev)
             self._total = tot
         lib = _lib.load()
-        _lib.check(lib.sow_reduce_batch(_ptr(self._d_descs), _ptr(self._d_starts), n, self._total, self._dt, _stream(self._dev)),
-                   "sow_reduce_batch")
+        _launch(self._dev, "sow_reduce_batch", lib.sow_reduce_batch, _ptr(self._d_descs), _ptr(self._d_starts), n, self._total,
+                self._dt)
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
@@ -264,8 +274,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         if beta == 0.0:
             out.zero_()
         return out
-    _lib.check(lib.sow_gemm(_ptr(A), max(A.stride(0), 1), int(trans_a), _ptr(B), max(B.stride(0), 1), int(trans_b), _ptr(out),
-                            max(out.stride(0), 1), _ptr(bias), M, N, K, float(alpha), float(beta), dt, _stream()), "sow_gemm")
+    _launch(dev, "sow_gemm", lib.sow_gemm, _ptr(A), max(A.stride(0), 1), int(trans_a), _ptr(B), max(B.stride(0), 1), int(trans_b),
+            _ptr(out), max(out.stride(0), 1), _ptr(bias), M, N, K, float(alpha), float(beta), dt)
     return out
 
 
@@ -285,8 +295,8 @@ def qr_thin(W: torch.Tensor, k: int, need_r: bool = True, out_dtype: Optional[to
     R = torch.empty((k, n), dtype=out_dtype, device=dev) if need_r else None
     nws = lib.sow_qr_workspace_bytes(m, n, k, _dt(W), int(need_r))
     ws = _ws(nws, dev)
-    _lib.check(lib.sow_qr_thin(_ptr(W), W.stride(0), m, n, _dt(W), k, _ptr(Q), k, _ptr(R), n, _DT[out_dtype], _ptr(ws),
-                               ws.numel(), _stream()), "sow_qr_thin")
+    _launch(dev, "sow_qr_thin", lib.sow_qr_thin, _ptr(W), W.stride(0), m, n, _dt(W), k, _ptr(Q), k, _ptr(R), n, _DT[out_dtype],
+            _ptr(ws), ws.numel())
     return Q, R
 
 
@@ -296,34 +306,33 @@ def zero_(tensors: Sequence[torch.Tensor]) -> None:
     ts = [t for t in tensors if t is not None and t.numel() > 0]
     if not ts:
         return
-    _need_gpu(*ts)
+    dev = _need_gpu(*ts)
     for t in ts:
         if not t.is_contiguous():
             raise ValueError("sow_amd.zero_: tensors must be contiguous")
     n = len(ts)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     sizes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in ts])
-    _lib.check(lib.sow_zero_state(ptrs, sizes, n, _stream()), "sow_zero_state")
+    _launch(dev, "sow_zero_state", lib.sow_zero_state, ptrs, sizes, n)
 
 
 def adamw_flat_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01, step: int = 1,
                 grad_scale: float = 1.0) -> None:
     lib = _lib.load()
-    _need_gpu(param, grad, exp_avg, exp_avg_sq)
-    _lib.check(lib.sow_adamw_flat(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, betas[0],
-                                  betas[1], eps, weight_decay, int(step), grad_scale, _dt(param), _dt(exp_avg), _stream()),
-               "sow_adamw_flat")
+    dev = _need_gpu(param, grad, exp_avg, exp_avg_sq)
+    _launch(dev, "sow_adamw_flat", lib.sow_adamw_flat, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr,
+            betas[0], betas[1], eps, weight_decay, int(step), grad_scale, _dt(param), _dt(exp_avg))
 
 
 def ttadam_dense_(param, grad, exp_avg, exp_avg_sq, *, beta1, beta2, eps, step_size, lr_times_wd, clamp_v: bool) -> None:
     lib = _lib.load()
-    _need_gpu(param, grad, exp_avg, exp_avg_sq)
+    dev = _need_gpu(param, grad, exp_avg, exp_avg_sq)
     for t in (param, grad, exp_avg, exp_avg_sq):
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise TypeError("ttadam_dense_ expects contiguous float32 tensors")
-    _lib.check(lib.sow_ttadam_dense(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), beta1, beta2,
-                                    eps, step_size, lr_times_wd, int(clamp_v), _stream()), "sow_ttadam_dense")
+    _launch(dev, "sow_ttadam_dense", lib.sow_ttadam_dense, _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(),
+            beta1, beta2, eps, step_size, lr_times_wd, int(clamp_v))
 
 
 def tt_kron_core(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -336,7 +345,7 @@ def tt_kron_core(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if (i, j) != (i2, j2):
         raise ValueError("tt_kron_core: physical dimensions differ")
     out = torch.empty((ra0 * rb0, i, j, ra1 * rb1), dtype=torch.float32, device=dev)
-    _lib.check(lib.sow_tt_kron_core(_ptr(a), _ptr(b), _ptr(out), ra0, rb0, i * j, ra1, rb1, _stream()), "sow_tt_kron_core")
+    _launch(dev, "sow_tt_kron_core", lib.sow_tt_kron_core, _ptr(a), _ptr(b), _ptr(out), ra0, rb0, i * j, ra1, rb1)
     return out
 
 
@@ -346,7 +355,7 @@ def absmax(x: torch.Tensor) -> float:
     dev = _need_gpu(x)
     x = x.contiguous().float()
     out = torch.empty(1, dtype=torch.float32, device=dev)
-    _lib.check(lib.sow_absmax(_ptr(x), x.numel(), _ptr(out), _stream()), "sow_absmax")
+    _launch(dev, "sow_absmax", lib.sow_absmax, _ptr(x), x.numel(), _ptr(out))
     return float(out.item())
 
 
@@ -359,17 +368,17 @@ def small_inverse(mats: torch.Tensor) -> torch.Tensor:
     if r != r2:
         raise ValueError("small_inverse expects square matrices")
     out = torch.empty_like(m)
-    _lib.check(lib.sow_small_inverse(_ptr(m), _ptr(out), b, r, _stream()), "sow_small_inverse")
+    _launch(dev, "sow_small_inverse", lib.sow_small_inverse, _ptr(m), _ptr(out), b, r)
     return out
 
 
 def axpby_(x: torch.Tensor, y: torch.Tensor, a: float, b: float) -> torch.Tensor:
     """y <- a*x + b*y"""
     lib = _lib.load()
-    _need_gpu(x, y)
+    dev = _need_gpu(x, y)
     if x.dtype != y.dtype or x.numel() != y.numel() or not (x.is_contiguous() and y.is_contiguous()):
         raise ValueError("axpby_: x and y must be contiguous, same dtype and size")
-    _lib.check(lib.sow_axpby(_ptr(x), _ptr(y), x.numel(), float(a), float(b), _dt(x), _stream()), "sow_axpby")
+    _launch(dev, "sow_axpby", lib.sow_axpby, _ptr(x), _ptr(y), x.numel(), float(a), float(b), _dt(x))
     return y
 
 

@@ -181,3 +181,43 @@ def reset_optimizer(optimizer, group_id):
             else:
                 state["step"] = 0
     ops.zero_(bufs)
+
+
+class SoWModel:
+    """prepare.py:181-185: thin holder (the reference derives it from PeftModel but skips its __init__)."""
+
+    def __init__(self, model, config: SoWConfig):
+        self.config = config
+        self.model = prepare_sow(model, config)
+
+
+def export_alignment(module, export_name, out_dir=None):
+    """prepare.py:224-245 (analysis dump, run_glue.py:55): percentage overlap between the left singular vectors of the
+    accumulator and those of the live update sum_i A_i B_i.  The products run on the HIP GEMM; the SVD is
+    torch.linalg.svd (utils.svd_weight).  The reference writes to a hard-coded home directory (:245); here the .npy goes
+    to `out_dir` (default $SOW_ALIGN_DIR or ./align) and the array is also returned."""
+    import os
+
+    import numpy as np
+
+    from .utils import svd_weight
+
+    if not isinstance(module, SoWLinear):
+        raise TypeError("Not a SoW layer")
+    with torch.no_grad():
+        A = torch.cat([w.data for w in module.downscale_weights], dim=1).contiguous()
+        B = torch.cat([w.data for w in module.upscale_weights], dim=0).contiguous()
+        update = ops.gemm(A, B)
+        if module.acc_upweight.numel() != 0:
+            weight = ops.gemm(module.acc_downweight.data, module.acc_upweight.data)
+        else:
+            weight = module.acc_downweight.data
+        u_upd, _, _ = svd_weight(update, module.rank)
+        u_w, _, _ = svd_weight(weight)
+        grid = ops.gemm(u_w.float().contiguous(), u_upd.float().contiguous(), trans_a=True).abs()
+        pct = (grid / grid.sum(dim=0)) * 100
+    arr = pct.cpu().numpy()
+    out_dir = out_dir or os.environ.get("SOW_ALIGN_DIR", "align")
+    os.makedirs(out_dir, exist_ok=True)
+    np.save(os.path.join(out_dir, export_name + ".npy"), arr)
+    return arr

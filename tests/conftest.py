@@ -21,6 +21,9 @@ def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         for k in z.files:
             a = z[k]
+            if a.dtype.kind in "US":
+                out[k] = [str(v) for v in a.tolist()]
+                continue
             out[k] = a.item() if a.ndim == 0 and a.dtype.kind in "iuf" and k not in _TENSOR_SCALARS else torch.from_numpy(np.array(a))
     return out
 

@@ -147,18 +147,17 @@ def test_grad_accumulation_beta():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_streaming_kernels_agree_with_generic_kernels(monkeypatch, dtype):
+def test_streaming_kernels_agree_with_generic_kernels(dtype):
     """A/B: the streaming chain kernels (chain2 bf16 / chain2f fp32) against the generic chain kernel on the same inputs."""
-    from sow_amd import ops
+    from sow_amd import _lib, ops
     T, di, do, r = 4608, 512, 1376, 50
     x, dy, A, B, b, _, _ = _rand_case(T, di, do, r, None, True, 55)
     g = lambda t: t.to(DEV, dtype)
     y2, h2 = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
     dx2 = ops.sow_backward(g(dy), g(x), h2, g(A), g(B), None, None, 0.5, True)[0]
-    monkeypatch.setenv("SOW_AMD_FORCE_CHAIN_V1", "1")
-    y1, h1 = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
-    dx1 = ops.sow_backward(g(dy), g(x), h1, g(A), g(B), None, None, 0.5, True)[0]
-    monkeypatch.delenv("SOW_AMD_FORCE_CHAIN_V1")
+    with _lib.switch(FORCE_CHAIN_V1=1):
+        y1, h1 = ops.sow_forward(g(x), g(A), g(B), None, None, g(b), 0.5)
+        dx1 = ops.sow_backward(g(dy), g(x), h1, g(A), g(B), None, None, 0.5, True)[0]
     tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
     assert rel_err(y2.float().cpu(), y1.float().cpu()) < tol and rel_err(dx2.float().cpu(), dx1.float().cpu()) < tol
     assert rel_err(h2.float().cpu().view(T, 64)[:, :50], h1.float().cpu().view(T, 64)[:, :50]) < tol
@@ -179,7 +178,7 @@ FUSED_H = [
 
 
 @pytest.mark.parametrize("idx", range(len(FUSED_H)))
-def test_dense_layer_with_in_kernel_projection(idx, monkeypatch):
+def test_dense_layer_with_in_kernel_projection(idx):
     """gemm2h (projection h = s x A computed inside the dense GEMM, one launch per pass) against the oracle and against
     the two-launch path (H-only chain + K-extended GEMM).  The last row of A is spiked so that a missing fix-up of its
     straddling 16-byte piece (the only piece whose tail crosses the end of the buffer) cannot hide in the tolerance."""
@@ -197,10 +196,10 @@ def test_dense_layer_with_in_kernel_projection(idx, monkeypatch):
     g = lambda t: None if t is None else t.to(DEV)
     y, h = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
     dx, dA, dB, db = ops.sow_backward(g(dyq), g(xq), h, g(Aq), g(Bq), g(adq), None, scale, bias)
-    monkeypatch.setenv("SOW_AMD_NO_FUSED_H", "1")
-    y0, h0 = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
-    dx0, dA0, dB0, db0 = ops.sow_backward(g(dyq), g(xq), h0, g(Aq), g(Bq), g(adq), None, scale, bias)
-    monkeypatch.delenv("SOW_AMD_NO_FUSED_H")
+    from sow_amd import _lib
+    with _lib.switch(NO_FUSED_H=1):
+        y0, h0 = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
+        dx0, dA0, dB0, db0 = ops.sow_backward(g(dyq), g(xq), h0, g(Aq), g(Bq), g(adq), None, scale, bias)
     tol = 2e-2
     assert rel_err(y.float().cpu(), y_ref) < tol and rel_err(dx.float().cpu(), dx_ref) < tol
     assert rel_err(dA.float().cpu(), dA_ref[0]) < tol and rel_err(dB.float().cpu(), dB_ref[0]) < tol
@@ -490,28 +489,31 @@ def test_gemm(dtype, ta, tb):
 
 @pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave", "small"])
 @pytest.mark.parametrize("tb", [False, True])
-def test_gemm_streaming_bf16(tb, kernel, monkeypatch):
+def test_gemm_streaming_bf16(tb, kernel):
     """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernels (gemm2: 8 waves, K < 2048; gemm3: one
-    wave per SIMD, K >= 2048; SOW_AMD_GEMM3 forces either on every shape): ragged M / N tiles, K tails of 8 and 32,
-    one- and two-stage K, alpha / beta / bias epilogue."""
-    from sow_amd import ops
+    wave per SIMD, K >= 2048; the GEMM3 / GEMM3S switches force either on every shape): ragged M / N tiles, K tails of 8
+    and 32, one- and two-stage K, alpha / beta / bias epilogue."""
+    from sow_amd import _lib, ops
     if kernel == "small":
-        monkeypatch.setenv("SOW_AMD_GEMM3S", "1")     # 128x128-tile kernel (gemm3s) on every shape
+        sel = dict(GEMM3S=1)                                  # 128x128-tile kernel (gemm3s) on every shape
     elif kernel != "auto":
-        monkeypatch.setenv("SOW_AMD_GEMM3S", "0")
-        monkeypatch.setenv("SOW_AMD_GEMM3", "1" if kernel == "1wave" else "0")
+        sel = dict(GEMM3S=0, GEMM3=1 if kernel == "1wave" else 0)
+    else:
+        sel = {}
     gen = torch.Generator().manual_seed(5)
-    for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40), (2100, 4500, 2056), (1000, 2056, 2304)):
-        a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
-        b = (torch.randn((N, K) if tb else (K, N), generator=gen) * 0.1).to(torch.bfloat16)
-        c0 = torch.randn(M, N, generator=gen).to(torch.bfloat16)
-        bias = torch.randn(N, generator=gen).to(torch.bfloat16)
-        ref = 0.5 * (a.float() @ (b.float().t() if tb else b.float())) + 2.0 * c0.float() + bias.float()
-        out = ops.gemm(a.to(DEV), b.to(DEV), trans_b=tb, out=c0.to(DEV).clone(), alpha=0.5, beta=2.0, bias=bias.to(DEV))
-        assert rel_err(out.float().cpu(), ref) < 2e-2, (M, N, K)
-        ref0 = a.float() @ (b.float().t() if tb else b.float())
-        out0 = ops.gemm(a.to(DEV), b.to(DEV), trans_b=tb)
-        assert rel_err(out0.float().cpu(), ref0) < 1e-2, (M, N, K)
+    with _lib.switch(**sel):
+        for (M, N, K) in ((40960, 256, 64), (16484, 1376, 1376), (20000, 520, 520), (45000, 72, 40), (2100, 4500, 2056), (1000, 2056, 2304)):
+            a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
+            b = (torch.randn((N, K) if tb else (K, N), generator=gen) * 0.1).to(torch.bfloat16)
+            c0 = torch.randn(M, N, generator=gen).to(torch.bfloat16)
+            bias = torch.randn(N, generator=gen).to(torch.bfloat16)
+            ref = 0.5 * (a.float() @ (b.float().t() if tb else b.float())) + 2.0 * c0.float() + bias.float()
+            out = ops.gemm(a.to(DEV), b.to(DEV), trans_b=tb, out=c0.to(DEV).clone(), alpha=0.5, beta=2.0, bias=bias.to(DEV))
+            assert rel_err(out.float().cpu(), ref) < 2e-2, (M, N, K)
+            ref0 = a.float() @ (b.float().t() if tb else b.float())
+            out0 = ops.gemm(a.to(DEV), b.to(DEV), trans_b=tb)
+            assert rel_err(out0.float().cpu(), ref0) < 1e-2, (M, N, K)
+    assert _lib.load().sow_get_switch(b"GEMM3S") == -1 and _lib.load().sow_get_switch(b"GEMM3") == -1
 
 
 def test_zero_state_and_reset_optimizer():

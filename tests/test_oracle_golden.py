@@ -210,3 +210,57 @@ def test_tt_linear():
     g = load_golden("tt_linear")
     y = O.tt_linear_forward(g["x"], _cores(g, "", 3) if False else [g["core0"], g["core1"], g["core2"]], 100, 60)
     assert y.shape == g["y"].shape and rel_err(y, g["y"]) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: caller protocols of BASELINE configs 4 / 5 replayed on the oracle (tests/oracle_backend.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("proto", ["glue", "finetune"])
+def test_protocol_trace_oracle(proto):
+    """run_glue.py:976-1002 / finetune.py:39-77 on the RoBERTa-shaped trio (768/3072, r = 8, fp32, keep): losses, factor
+    and bias gradients, dense-accumulator probes after every accumulate(), scale -> 1/rank schedule, final factors."""
+    import oracle_backend
+    import protocols as P
+    g = load_golden("protocol_" + proto)
+
+    def set_draw(m, draw):
+        m.next_draws = [draw]
+
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    errs = P.replay_and_check(oracle_backend.BACKEND, g, proto, "cpu", set_draw,
+                              dict(loss=1e-6, grad=1e-5, acc=1e-5, final=1e-5))
+    assert len(errs) > 20
+
+
+def test_checkpointed_layer_oracle():
+    """Activation checkpointing (BASELINE config 5; simple_train.py:423): the reference's gradients are bit-identical with
+    and without torch.utils.checkpoint (asserted when the fixture was made); the oracle reproduces them."""
+    g = load_golden("checkpoint_layer")
+    acc = O.decompose_keep(g["W"])
+    xt = torch.tanh(g["x"])
+    y = O.sow_forward(xt, [g["A"]], [g["B"]], acc, None, g["scale"], None)
+    assert rel_err(y, g["plain_y"]) < TOL
+    dxt, dA, dB, _ = O.sow_backward(g["dy"], xt, [g["A"]], [g["B"]], acc, None, g["scale"], False)
+    assert rel_err(dxt * (1 - xt * xt), g["plain_dx"]) < TOL
+    assert rel_err(dA[0], g["plain_dA"]) < TOL and rel_err(dB[0], g["plain_dB"]) < TOL
+
+
+def test_tt_newton_and_reciprocal():
+    """a11: TensorTrain.sqrt / sqrtinv / reciprocal (tt.py:279-341, 480-494) against reference outputs; the first case is
+    the one tests/tt_test.py:1-13 prints."""
+    g = load_golden("tt_newton")
+    a = torch.arange(2 * 2 * 2 * 3 * 3 * 3).reshape(2, 2, 2, 3, 3, 3).float()
+    cores = O.tt_from_tensor(a, [1, 4, 4, 1])
+    got = O.tt_reconstruct(O.tt_sqrt(cores))
+    print("t216", rel_err(got, g["t216_sqrt_rec"]))
+    pos = [g[f"pos_core{i}"] for i in range(3)]
+    for name, fn in (("sqrt", lambda c: O.tt_sqrt(c)), ("sqrt_it2", lambda c: O.tt_sqrt(c, max_iter=2)),
+                     ("sqrtinv", lambda c: O.tt_sqrtinv(c)), ("sqrtinv_it2", lambda c: O.tt_sqrtinv(c, threshold=None, max_iter=2))):
+        out = fn(pos)
+        assert O._tt_meta(out)[0] == [int(r) for r in g[f"pos_{name}_ranks"]], name
+        e = rel_err(O.tt_reconstruct(out), g[f"pos_{name}_rec"])
+        print(name, e)
+        assert e < 1e-4, (name, e)
+    rec = O.tt_reciprocal([g[f"recip_in{i}"] for i in range(3)])
+    for i in range(3):
+        assert rel_err(rec[i], g[f"recip_out{i}"]) < 1e-5

@@ -1,2 +1,2 @@
 from sow_amd.layer import SoWLinear  # noqa: F401
-from sow_amd.prepare import SoWConfig, accumulate, load_sow, prepare_sow  # noqa: F401
+from sow_amd.prepare import SoWConfig, SoWModel, accumulate, export_alignment, load_sow, prepare_sow  # noqa: F401

@@ -1,1 +1,4 @@
-from sow_amd.utils import closest_factorization, pad_matrix, qr_weight, svd_weight, unpad_matrix  # noqa: F401
+from sow_amd.utils import (  # noqa: F401
+    __colorized_str__, closest_factorization, generate_rank_k, left_unfolding, pad_matrix, perturbe_random, qr_weight,
+    randhaar, randuptri, right_unfolding, svd_weight, unfolding, unpad_matrix,
+)
