@@ -167,7 +167,9 @@ class SoWLinear(nn.Module):
             self.virtual_rank = min(self.virtual_rank + self.rank * self.n_iter, self.in_features, self.out_features)
         else:                                                              # sow.py:151-153
             self.acc_downweight = nn.Parameter(acc, requires_grad=False)
-            self.acc_upweight = nn.Parameter(torch.empty(0), requires_grad=False)
+            # zero-numel placeholder as in the reference (default dtype), but on the layer's device so that a state dict
+            # taken after accumulate() does not mix devices
+            self.acc_upweight = nn.Parameter(torch.empty(0, device=acc.device), requires_grad=False)
 
         # new factors: B <- 0 (sow.py:159), A <- Q[:, :r] of a fresh Gaussian (sow.py:161-172) or a Gaussian (:174)
         new_down = [torch.zeros_like(w) for w in self.downscale_weights]

@@ -118,7 +118,10 @@ def load_sow(model, checkpoint_path):
         for part in name.split("."):
             obj = getattr(obj, part)
         if obj.numel() == 0:
-            new_param = nn.Parameter(tensor.clone(), requires_grad=False)
+            # the reference loads before model.to(device) (simple_train.py:357 vs :425), so its clone stays wherever
+            # safetensors put it; here the replacement lands on the device the placeholder already lives on, so that
+            # loading into a model that is already on the GPU works too
+            new_param = nn.Parameter(tensor.clone().to(obj.device), requires_grad=False)
             if "." in name:
                 parent, child = name.rsplit(".", 1)
                 setattr(modules[parent], child, new_param)

@@ -171,7 +171,7 @@ def test_save_pretrained_round_trip_after_gpu_accumulate(tmp_path):
     sd_a, sd_b = model.state_dict(), fresh.state_dict()
     assert list(sd_a.keys()) == list(sd_b.keys())
     for k in sd_a:
-        assert sd_a[k].shape == sd_b[k].shape and torch.equal(sd_a[k], sd_b[k]), k
+        assert sd_a[k].shape == sd_b[k].shape and sd_a[k].device == sd_b[k].device and torch.equal(sd_a[k], sd_b[k]), k
     opt2 = torch.optim.AdamW(groups(fresh), weight_decay=0.0)
     opt2.load_state_dict(torch.load(str(tmp_path / "optimizer.pt"), weights_only=True))
     for net, o in ((model, opt), (fresh, opt2)):
