@@ -6,14 +6,23 @@ rank 50; 32 x (512->512), 16 x (512->1376), 8 x (1376->512), reference scripts/c
 at batch 128 x seq 256 = 32768 tokens per GPU, bf16.  One step = forward of all 56 layers in model
 order, backward of all 56 in reverse order (every layer has its own x / dY buffers, so nothing is
 re-read from cache that a real model would not have; the token-slab partial sums of the weight gradients
-are reduced in one batched launch at the end of backward -- `--reduce layer` does it per layer, 3 % slower,
-bit-identical gradients), and -- for N > 1 -- ONE RCCL all-reduce of the flat factor-gradient bucket.  Inputs are resident in HBM before the timed region.  The step is
-captured in a HIP graph after warm-up (no host work in the timed region).
+are reduced in one batched launch at the end of backward), and -- for N > 1 -- ONE RCCL all-reduce of the
+flat factor-gradient bucket.  Inputs are resident in HBM before the timed region.  The step is captured in a
+HIP graph after warm-up (no host work in the timed region).
+
+Layers that are independent INSIDE a decoder block -- {q, k, v} and {gate, up}; o and down stand alone -- are issued
+through the grouped C-ABI calls (sow_forward_group / sow_backward_group: one grid per kernel for the group; every layer
+keeps its own x / dY / y, so the algorithmic bytes are unchanged): 4 launches per direction per block instead of 7.
+`--group none` issues every layer on its own.
 
 Prints ONE JSON line.  `value` = tokens/s over all ranks (T * N / step time); `gflops` = the
-algorithmic 6*T*r*(d_in+d_out) count per second.
+algorithmic 6*T*r*(d_in+d_out) count per second.  At N = 1 the same line also carries, as extra
+keys measured in the same process after the headline: `dense` (the steady state after the first accumulate(): dense
+frozen accumulator, MFMA-bound), `fp32` (the exact-fp32 parity path against the 157 TF fp32 matrix peak) and `train`
+(a full llama_60m training step through the module-swap surface) -- skip them with --only-headline.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -26,11 +35,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-# WRITE_SIZE, see profiles/); None until collected for the current kernel version.
-TRAFFIC_BYTES_PER_LAUNCH = 97.9e6  # profiles/r01_pmc_hbm_fetch_write_v3.txt (bf16, chain2_kernel<false>)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_TFLOPS = 157.0    # fp32 matrix peak
+# HBM bytes per launch of the roofline kernel, from the rocprofv3 PMC passes made at the commit named inside the file
+# (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_traffic.py); absent or for another kernel -> null in the line.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 LLAMA_60M = dict(hidden=512, inter=1376, layers=8)
+BLOCK_NAMES = ["q", "k", "v", "o", "gate", "up", "down"]
+BLOCK_GROUPS = [[0, 1, 2], [3], [4, 5], [6]]   # model-independent layers inside one decoder block
 
 
 def layer_shapes():
@@ -49,37 +62,33 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-headline", action="store_true", help="skip the dense / fp32 / train sections (N = 1 adds them by default)")
     ap.add_argument("--acc", default="none", choices=["none", "dense"], help="accumulator state of the layers")
     ap.add_argument("--mode", default="stack", choices=["stack", "train"],
                     help="stack: the 56-layer SoWLinear hot path (headline); train: a full llama_60m training step "
                          "through the module-swap surface (prepare_sow, autograd, AdamW, accumulate), secondary figure")
     ap.add_argument("--accumulate-every", type=int, default=4, help="--mode train: SoW accumulation period in steps")
     ap.add_argument("--fused-factors", action="store_true",
-                    help="--mode train, 1 GPU: factor group in a FactorBucket (gradients written straight into one flat buffer, "
-                         "one batched reduction, one fused AdamW kernel) instead of torch.optim.AdamW's second param group")
+                    help="--mode train: factor group in a FactorBucket (gradients written straight into one flat buffer, one "
+                         "batched reduction, one fused AdamW kernel, ONE all-reduce of the bucket at N > 1 with DDP covering "
+                         "the other parameters) instead of torch.optim.AdamW's second param group")
     ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
                     help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
                          "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2: weight-gradient kernels on a side stream (measured: -4 %%; only their small reduction on a side stream: -16 %% -- cross-stream edges of a HIP graph cost more than the 5-us kernel they hide)")
+    ap.add_argument("--group", choices=["block", "none"], default="block",
+                    help="block: {q,k,v} and {gate,up} of a decoder block share launches (grouped C-ABI calls); none: one call per layer")
     return ap.parse_args()
 
 
 class Stack:
-    """The 56-layer SoWLinear stack with resident synthetic inputs."""
+    """The 56-layer SoWLinear stack with resident synthetic inputs and static output buffers."""
 
-    def __init__(self, shapes, T, r, dtype, device, acc, streams=1, reduce="layer"):
+    def __init__(self, shapes, T, r, dtype, device, acc, reduce="batch", group="block"):
         from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
-        self.streams = streams
         self.deferred = ops.DeferredReduce() if reduce == "batch" else None
-        self.side = torch.cuda.Stream(device=device) if streams > 1 else None
         kind = 2 if acc == "dense" else 0
-        # per-layer workspaces (dh + slab partials): the split backward keeps them alive across two streams
-        self.ws = [torch.empty(ops.workspace_bytes(T, di, do, r, 0, kind, dtype) + 256, dtype=torch.uint8, device=device)
-                   for di, do in shapes]
-        self.dx = {di: [torch.empty(T, di, dtype=dtype, device=device) for _ in range(4)] for di in {s[0] for s in shapes}}
         g = torch.Generator(device=device)
         self.x, self.dy, self.A, self.B, self.W = [], [], [], [], []
         params = []
@@ -93,51 +102,46 @@ class Stack:
             self.B.append(torch.nn.Parameter(b.to(dtype).contiguous()))
             params += [self.A[-1], self.B[-1]]
             self.W.append((torch.randn(d_in, d_out, generator=g, device=device) * 0.02).to(dtype) if acc == "dense" else None)
-        self.bucket = FactorBucket(params)  # grads are views into one flat buffer
-        self.h = [None] * len(shapes)
+        self.bucket = FactorBucket(params)  # params / grads are views into two flat buffers
+        # outputs rotate through a few buffers per width (a real model frees activations it no longer needs)
+        widths = {s[0] for s in shapes} | {s[1] for s in shapes}
+        pool = {d: [torch.empty(T, d, dtype=dtype, device=device) for _ in range(4)] for d in widths}
+        self.calls = []
+        for li, (d_in, d_out) in enumerate(shapes):
+            ws = torch.empty(ops.workspace_bytes(T, d_in, d_out, r, 0, kind, dtype) + 256, dtype=torch.uint8, device=device)
+            self.calls.append(ops.LayerCall(self.x[li], self.A[li].data, self.B[li].data, acc_down=self.W[li], scale=1.0,
+                                            y=pool[d_out][li % 4], dy2=self.dy[li], dx=pool[d_in][(li + 2) % 4],
+                                            out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0, workspace=ws))
+        nb = len(BLOCK_NAMES)
+        layout = BLOCK_GROUPS if group == "block" else [[i] for i in range(nb)]
+        self.group_layers = [[blk * nb + i for i in idx] for blk in range(len(shapes) // nb) for idx in layout]
+        self.groups = [ops.LayerGroup([self.calls[li] for li in ids]) for ids in self.group_layers]
 
-    def forward_all(self):
-        from sow_amd import ops
-        for li in range(len(self.shapes)):
-            _, self.h[li] = ops.sow_forward(self.x[li], self.A[li].data, self.B[li].data, self.W[li], None, None, 1.0)
+    def forward_all(self, only=None):
+        for gi, grp in enumerate(self.groups):
+            if only is None or gi in only:
+                grp.forward()
 
-    def backward_all(self):
-        """Backward in reverse layer order.  The data-gradient kernel of a layer (dX: what the previous
-        layer's backward waits for in a real model) stays on the main stream; with --streams 2 the
-        weight-gradient kernels (skinny-TN + reduce), which nothing in backprop depends on, run on a side
-        stream ordered by an event -- the true dependency structure of a training step."""
-        from sow_amd import _lib, ops
-        main = torch.cuda.current_stream()
-        if self.side is not None:
-            self.side.wait_stream(main)
-        for n, li in enumerate(reversed(range(len(self.shapes)))):
-            args = (self.dy[li], self.x[li], self.h[li], self.A[li].data, self.B[li].data, self.W[li], None, 1.0, False)
-            kw = dict(out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0, workspace=self.ws[li],
-                      dx=self.dx[self.shapes[li][0]][n % 4])
-            if self.deferred is not None:
-                ops.sow_backward(*args, phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL, **kw)
-                self.deferred.add(self.x[li], self.B[li].data, kw["out"], 0.0, self.ws[li], self.W[li], None)
-            elif self.side is None:
-                ops.sow_backward(*args, **kw)
-            else:
-                ops.sow_backward(*args, phases=_lib.BWD_DATA, **kw)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(ev)
-                    ops.sow_backward(*args, phases=_lib.BWD_WEIGHTS, **kw)
-        if self.deferred is not None:
+    def backward_all(self, only=None, phases=None):
+        """Backward in reverse order; per group the data-gradient kernels (dX: what the previous layer's backward
+        waits for in a real model) run first, then the weight-gradient partial sums; ONE batched reduction at the end."""
+        from sow_amd import _lib
+        ph = phases if phases is not None else (_lib.BWD_DATA | (_lib.BWD_WEIGHTS_PARTIAL if self.deferred is not None else _lib.BWD_WEIGHTS))
+        for gi in reversed(range(len(self.groups))):
+            if only is not None and gi not in only:
+                continue
+            self.groups[gi].backward(ph)
+            if self.deferred is not None and phases is None:
+                for li in reversed(self.group_layers[gi]):
+                    c = self.calls[li]
+                    self.deferred.add(self.x[li], self.B[li].data, (self.A[li].grad, self.B[li].grad, None), 0.0, c.workspace,
+                                      self.W[li], None)
+        if self.deferred is not None and phases is None:
             self.deferred.run()
-        if self.side is not None:
-            main.wait_stream(self.side)
 
     def step(self):
         self.forward_all()
         self.backward_all()
-
-
-BWD_LABEL = {"layer": "backward: chain kernel + tn_partial + tn_reduce, x56 each",
-             "batch": "backward: chain kernel + tn_partial x56 each, one batched tn_reduce"}
 
 
 def algorithmic(shapes, T, r, es, acc):
@@ -157,6 +161,24 @@ def time_region(fn, iters, stream):
     e1.record(stream)
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
+
+def time_graph(fn, stream, reps=5):
+    """ms per replay of a HIP graph of fn() (launch gaps as in the timed step), events on the launch stream."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        g.replay()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def cpu_baseline(shapes, T, r):
@@ -187,12 +209,20 @@ def cpu_baseline(shapes, T, r):
                 sample=f"1 fwd+bwd pass over the 56 llama_60m SoWLinear shapes, T={T}, fp32, torch-CPU oracle, {dt:.2f} s")
 
 
-def train_mode(args, world, rank, device):
+def train_mode(args, world, rank, device, steps=None, warmup=None, quiet=False):
     """Caller protocol of the reference's scripts/simple_train.py:316-333, 389-405, 425-428, 502-506, 566-572,
     596-650 with synthetic tokens: llama_60m from the JSON's numbers, prepare_sow(rank 50, normal_QR),
-    bf16 cast after the swap, AdamW with two groups, accumulate + reset_optimizer between backward and step."""
+    bf16 cast after the swap, AdamW with two groups, accumulate + reset_optimizer between backward and step.
+
+    --fused-factors (any world size): the factor group lives in a FactorBucket -- SoWLinear's backward writes the factor
+    gradients straight into ONE flat buffer, DDP covers only the non-factor parameters (the factors are on its ignore
+    list), the bucket's single all-reduce is issued from backward as soon as the last attached layer has queued its
+    partial sums (overlapping the embedding / lm_head gradient work and DDP's own buckets), the re-initialised A is
+    broadcast after accumulate(), and the factor group steps in one fused AdamW kernel."""
     import transformers
     from sow_amd import SoWConfig, SoWLinear, accumulate, prepare_sow, reset_optimizer
+    steps = steps or args.steps
+    warmup = warmup if warmup is not None else args.warmup
     torch.manual_seed(42)
     cfg = transformers.LlamaConfig(hidden_size=512, intermediate_size=1376, num_hidden_layers=8, num_attention_heads=8,
                                    vocab_size=32000, max_position_embeddings=1024, rms_norm_eps=1e-6,
@@ -209,18 +239,21 @@ def train_mode(args, world, rank, device):
                 ids.add(id(wgt))
     model = model.to(device=device, dtype=torch.bfloat16)
     trainable = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
-    fused = args.fused_factors and world == 1
+    fused = args.fused_factors
+    inner = model
     if fused:
         from sow_amd.dp import FactorBucket
         from sow_amd.optimizer import FactorAdamW
         bucket = FactorBucket(special)
-        bucket.attach(model)
+        bucket.attach(model, auto_all_reduce=world > 1)
         fopt = FactorAdamW(bucket, lr=1e-3, weight_decay=0.0)
         opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0}])
     else:
         opt = torch.optim.AdamW([{"params": trainable, "lr": 1e-3, "weight_decay": 0.0},
                                  {"params": special, "lr": 1e-3, "weight_decay": 0.0}])
     if world > 1:
+        if fused:
+            bucket.exclude_from_ddp(model)
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], output_device=device.index,
                                                           broadcast_buffers=False)
     batch, seq = 128, 256
@@ -232,29 +265,28 @@ def train_mode(args, world, rank, device):
         loss = model(input_ids=tokens, labels=tokens.clone()).loss
         loss.backward()
         step_no[0] += 1
+        gscale = bucket.wait() if fused else 1.0          # the bucket's all-reduce was issued inside backward
         if step_no[0] % args.accumulate_every == 0:      # simple_train.py:618-626 (GA = 1)
+            accumulate(inner)                             # an attached bucket finalizes before and rebinds after
             if fused:
-                bucket.finalize()
-            accumulate(model.module if world > 1 else model)
-            if fused:
-                bucket.rebind()
+                bucket.broadcast_factors()
                 fopt.reset_state()
             else:
                 reset_optimizer(opt, group_id=1)
         opt.step()
         opt.zero_grad()
         if fused:
-            fopt.step()
+            fopt.step(grad_scale=gscale)
             bucket.zero_grad()
         return loss
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -264,46 +296,63 @@ def train_mode(args, world, rank, device):
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    ms = elapsed / args.steps * 1e3
-    if rank == 0:
-        print(json.dumps({
-            "metric": "llama_60m --architecture sow rank=50 training tokens/s (full step, synthetic tokens)",
-            "value": batch * seq * world / (ms * 1e-3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "llama_60m (HF LlamaForCausalLM from config) + prepare_sow rank 50, batch 128 x seq 256, "
-                                   f"AdamW 2 groups, accumulate every {args.accumulate_every} steps",
-                       "parallelism": f"ddp{world}", "fused_factors": bool(fused), "final_loss": float(loss.detach())}}))
+    ms = elapsed / steps * 1e3
+    out = {
+        "metric": "llama_60m --architecture sow rank=50 training tokens/s (full step, synthetic tokens)",
+        "value": batch * seq * world / (ms * 1e-3), "unit": "tokens/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "llama_60m (HF LlamaForCausalLM from config) + prepare_sow rank 50, batch 128 x seq 256, "
+                               f"AdamW 2 groups, accumulate every {args.accumulate_every} steps",
+                   "parallelism": f"ddp{world}", "fused_factors": bool(fused), "final_loss": float(loss.detach())}}
+    if rank == 0 and not quiet:
+        print(json.dumps(out))
+    del model, inner, opt
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one process per GPU; ranks beyond the visible devices (a rehearsal of the N > 1 path on a 1-GPU box) share them
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-    if world > 1:
-        backend = os.environ.get("SOW_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (xGMI); "gloo" only for rehearsals
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    es = 2 if args.dtype == "bf16" else 4
+def launch_kinds(stack):
+    """Distinct launch kinds of one decoder block: (label, group index within block 0, layer shapes)."""
+    ngroups = len(stack.groups) // LLAMA_60M["layers"]
+    kinds = []
+    for gi in range(ngroups):
+        ids = stack.group_layers[gi]
+        names = "+".join(BLOCK_NAMES[i % len(BLOCK_NAMES)] for i in ids)
+        di, do = stack.shapes[ids[0]]
+        kinds.append((f"{names} {len(ids)}x({di}->{do})", gi, [stack.shapes[i] for i in ids]))
+    return kinds
+
+
+def per_launch_table(stack, stream, T, r, es):
+    """us / GB/s / fraction of the HBM peak per launch kind (HIP-graph replay of the 8 instances of the kind, one per
+    decoder block, events on the launch stream).  Algorithmic bytes per launch: chain kernels T*(D1 + D2 + r)*s per
+    layer; weight-gradient partial kernel T*(d_in + d_out + 2 r)*s per layer (x and dY once, h and dh once)."""
+    from sow_amd import _lib
+    nblk = LLAMA_60M["layers"]
+    ngroups = len(stack.groups) // nblk
+    table = {}
+    for label, gi, shp in launch_kinds(stack):
+        only = {blk * ngroups + gi for blk in range(nblk)}
+        chain_bytes = sum(T * (di + do + r) * es for di, do in shp)
+        tn_bytes = sum(T * (di + do + 2 * r) * es for di, do in shp)
+        for tag, fn, nbytes in (
+                ("fwd chain", lambda: stack.forward_all(only), chain_bytes),
+                ("bwd chain (dX)", lambda: stack.backward_all(only, _lib.BWD_DATA), chain_bytes),
+                ("bwd weight partials", lambda: stack.backward_all(only, _lib.BWD_WEIGHTS_PARTIAL), tn_bytes)):
+            us = time_graph(fn, stream) / nblk * 1e3
+            gbs = nbytes / us / 1e3
+            table[f"{tag}: {label}"] = {"us": round(us, 2), "GB/s": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 3),
+                                        "algorithmic_MB": round(nbytes / 1e6, 2)}
+    return table
+
+
+def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, detail):
+    """Build the stack, capture the step, time `steps` replays (barrier + synchronize on both sides, max over ranks)."""
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    es = 2 if dtype_name == "bf16" else 4
     shapes = layer_shapes()
     T = args.tokens
-
-    from sow_amd import _lib
-    _lib.load()  # fail loudly when the HIP library is missing
-    if args.mode == "train":
-        train_mode(args, world, rank, device)
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    stack = Stack(shapes, T, args.rank, dtype, device, args.acc, args.streams, args.reduce)
+    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
 
@@ -313,8 +362,9 @@ def main():
             stack.bucket.wait()
 
     graph = None
+    res = {}
     with torch.cuda.stream(stream):
-        for _ in range(max(args.warmup, 1)):   # W untimed warm-up steps (also sets kernel attributes)
+        for _ in range(max(warmup, 1)):   # W untimed warm-up steps (also sets kernel attributes)
             stack.step()
             comm()
         torch.cuda.synchronize()
@@ -337,7 +387,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             one_step()
         torch.cuda.synchronize()
         if world > 1:
@@ -347,28 +397,93 @@ def main():
             tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+        ms = elapsed / steps * 1e3
+        flops, nbytes = algorithmic(shapes, T, args.rank, es, acc)
+        res.update(ms_per_step=ms, flops=flops, nbytes=nbytes, graph=graph is not None, T=T, shapes=shapes, es=es)
+        if rank == 0 and detail:
+            it = max(3, min(steps, 10))
+            nl = len(stack.groups)
+            res["fwd_ms"] = time_region(stack.forward_all, it, stream)
+            res["bwd_ms"] = time_region(stack.backward_all, it, stream)
+            res["n_fwd_launches"] = nl
+            if acc == "none" and dtype_name == "bf16":
+                res["per_launch"] = per_launch_table(stack, stream, T, args.rank, es)
+            if acc == "dense":
+                # layers whose forward is exactly ONE gemm2h launch (N <= 512: 40 of the 56); flops of one launch =
+                # dense product + rank-r projection and extension
+                one = [gi for gi, ids in enumerate(stack.group_layers) if all(shapes[i][1] <= 512 for i in ids)]
+                n_l = sum(len(stack.group_layers[gi]) for gi in one)
+                t = time_region(lambda: stack.forward_all(set(one)), it, stream)
+                fl = sum(2 * T * shapes[i][0] * shapes[i][1] + 2 * T * args.rank * (shapes[i][0] + shapes[i][1])
+                         for gi in one for i in stack.group_layers[gi])
+                res["gemm2h"] = dict(avg_launch_ms=t / n_l, launches=n_l, tflops=fl / (t * 1e-3) / 1e12)
+    del stack, graph
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
-        # per-kernel timing with HIP events on the launch stream (rank 0, after the timed region).
-        # forward_all launches exactly one kernel per layer (chain2_kernel<false>), so its average is a
-        # single-kernel figure that can be checked against the rocprofv3 stats under profiles/.
-        groups = {}
-        if rank == 0:
-            it = max(3, min(args.steps, 10))
-            groups["forward: chain kernel x56"] = time_region(stack.forward_all, it, stream)
-            groups[BWD_LABEL[args.reduce]] = time_region(stack.backward_all, it, stream)
 
-    ms = elapsed / args.steps * 1e3
-    flops, nbytes = algorithmic(shapes, T, args.rank, es, args.acc)
+def traffic_record(kernel_name):
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+        k = rec.get("kernels", {}).get(kernel_name)
+        if k:
+            return k["hbm_bytes_per_launch"], {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "commit": rec.get("commit"),
+                                               "launches_profiled": k.get("launches"), "grouping": rec.get("group")}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; ranks beyond the visible devices (a rehearsal of the N > 1 path on a 1-GPU box) share them
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        backend = os.environ.get("SOW_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (xGMI); "gloo" only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+
+    from sow_amd import _lib
+    _lib.load()  # fail loudly when the HIP library is missing
+    if args.mode == "train":
+        train_mode(args, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    head = measure_stack(args, args.dtype, args.acc, world, rank, device, args.steps, args.warmup, detail=True)
+    ms, T, shapes, es = head["ms_per_step"], head["T"], head["shapes"], head["es"]
     if rank == 0:
         n_layers = len(shapes)
-        fwd_ms = groups["forward: chain kernel x56"]
-        # dominant kernel (largest total time in profiles/r01_bench_v2_kernel_stats.csv): the forward chain
-        # kernel.  Algorithmic bytes per launch = T*(d_in + d_out + r)*s averaged over the 56 layers
-        # (x read once, y written once, h saved once).
-        kname = "sow::chain2_kernel<false> (fused forward chain)" if args.dtype == "bf16" else "sow::chain2f_kernel<false> (fused forward chain, fp32)"
-        kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / n_layers
-        kms = fwd_ms / n_layers
-        achieved = kbytes / (kms * 1e-3) / 1e9
+        if args.acc == "dense":
+            # steady state after the first accumulate(): MFMA-bound; dominant kernel by total time = gemm2h
+            kname = "sow::gemm2h_kernel<false> (dense-accumulator forward, projection fused)"
+            g2h = head["gemm2h"]
+            roof = {"bound": "mfma", "kernel": kname, "achieved": g2h["tflops"], "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": g2h["tflops"] / MFMA_BF16_TFLOPS, "traffic": None, "avg_launch_ms": g2h["avg_launch_ms"],
+                    "launches_timed": g2h["launches"]}
+        else:
+            # dominant kernel (largest total time in profiles/): the forward chain kernel.  Algorithmic bytes per launch =
+            # sum over the launch's layers of T*(d_in + d_out + r)*s (x read once, y written once, h saved once).
+            kernel_sym = "chain2_kernel<false>" if args.dtype == "bf16" else "chain2f_kernel<false>"
+            kname = f"sow::{kernel_sym} (fused forward chain{', fp32' if args.dtype != 'bf16' else ''})"
+            nl = head["n_fwd_launches"]
+            kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / nl
+            kms = head["fwd_ms"] / nl
+            achieved = kbytes / (kms * 1e-3) / 1e9
+            traffic, tsrc = traffic_record(kernel_sym) if (args.dtype == "bf16" and args.group == "block") else (None, None)
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": kms,
+                    "launches_per_step": nl, "layers_per_step": n_layers, "algorithmic_bytes_per_launch": kbytes}
         out = {
             "metric": "SoWLinear fwd+bwd tokens/s, llama_60m rank=50 (56-layer SoWLinear stack)",
             "value": T * world / (ms * 1e-3),
@@ -384,15 +499,44 @@ def main():
             "data": "synthetic",
             "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
-                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": graph is not None, "streams": args.streams, "weight_grad_reduce": args.reduce},
-            "gflops": flops * world / (ms * 1e-3) / 1e9,
-            "algorithmic_gbytes_per_step": nbytes / 1e9,
-            "step_hbm_gbs": nbytes / (ms * 1e-3) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH if (args.dtype == "bf16" and args.acc == "none") else None,
-                         "avg_launch_ms": kms, "algorithmic_bytes_per_launch": kbytes},
-            "kernel_groups_ms": groups,
+                       "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": head["graph"],
+                       "weight_grad_reduce": args.reduce,
+                       "launch_grouping": "per decoder block: {q,k,v} {o} {gate,up} {down}" if args.group == "block" else "one call per layer"},
+            "gflops": head["flops"] * world / (ms * 1e-3) / 1e9,
+            "algorithmic_gbytes_per_step": head["nbytes"] / 1e9,
+            "step_hbm_gbs": head["nbytes"] / (ms * 1e-3) / 1e9,
+            "step_hbm_frac": head["nbytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": roof,
+            "kernel_groups_ms": {"forward (chain kernels)": head["fwd_ms"],
+                                 "backward (chain kernels + weight-gradient partials + one batched reduce)": head["bwd_ms"]},
         }
+        if "per_launch" in head:
+            out["per_launch"] = head["per_launch"]
+    extras = world == 1 and not args.only_headline and args.dtype == "bf16" and args.acc == "none"
+    if extras:
+        k = max(3, min(args.steps, 10))
+        d = measure_stack(args, "bf16", "dense", 1, 0, device, k, 2, detail=True)
+        g2h = d["gemm2h"]
+        out["dense"] = {
+            "what": "steady state after the first accumulate(): dense frozen accumulator + live rank-50 factors (prepare.py:120)",
+            "ms_per_step": d["ms_per_step"], "steps": k, "tokens_per_s": T / (d["ms_per_step"] * 1e-3),
+            "tflops": d["flops"] / (d["ms_per_step"] * 1e-3) / 1e12,
+            "frac_of_bf16_mfma_peak": d["flops"] / (d["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "sow::gemm2h_kernel<false> (one launch per forward pass, N <= 512)",
+                         "achieved": g2h["tflops"], "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": g2h["tflops"] / MFMA_BF16_TFLOPS, "traffic": None, "avg_launch_ms": g2h["avg_launch_ms"],
+                         "launches_timed": g2h["launches"]}}
+        f = measure_stack(args, "f32", "none", 1, 0, device, max(3, min(args.steps, 5)), 2, detail=False)
+        out["fp32"] = {"what": "the same stack in exact fp32 (the 1e-5 parity path)", "ms_per_step": f["ms_per_step"],
+                       "tflops": f["flops"] / (f["ms_per_step"] * 1e-3) / 1e12,
+                       "frac_of_fp32_mfma_peak": f["flops"] / (f["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_TFLOPS}
+        try:
+            t = train_mode(args, 1, 0, device, steps=max(3, min(args.steps, 10)), warmup=3, quiet=True)
+            out["train"] = {"what": t["config"]["workload"], "ms_per_step": t["ms_per_step"], "tokens_per_s": t["value"],
+                            "fused_factors": t["config"]["fused_factors"]}
+        except Exception as e:  # transformers missing or too old on the box: the headline must still print
+            out["train"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shapes, T, args.rank)
         print(json.dumps(out))

@@ -127,6 +127,37 @@ int sow_backward_reduce_desc(void* dA, void* dB, void* dbias, int64_t T, int d_i
                              int* blocks_out);
 int sow_reduce_batch(const void* descs, const int* starts, int n, int total_blocks, int dtype, void* stream);
 
+/* Grouped calls: n INDEPENDENT SoWLinear invocations in as few launches as possible -- the q / k / v projections of
+ * an attention block (sow.py:107-126 called three times on the same hidden state by the HF model), gate / up of an MLP,
+ * and their backward passes.  Each element carries exactly the arguments of sow_forward / sow_backward_ex for its
+ * layer (fields a direction does not use are ignored).  Semantics = the n single calls, in any order; results are
+ * bit-identical to them.  Layers that run the bf16 streaming kernels (no accumulator, r_live <= 64, T > 8192) share one
+ * grid per kernel, up to 4 layers at a time: a launch costs ~8 us of ramp + first-load latency + write drain whatever
+ * its size, which a 3-layer grid pays once.  Every other layer is forwarded to the single-layer entry point. */
+typedef struct sow_layer_args {
+  const void* x;        /* [T, d_in]                                      */
+  const void* A;        /* [d_in, r_live]                                 */
+  const void* B;        /* [r_live, d_out]                                */
+  const void* acc_down; /* per acc_kind, or NULL                          */
+  const void* acc_up;
+  const void* bias;     /* [d_out] or NULL                                */
+  void* y;              /* forward output [T, d_out]                      */
+  void* h_save;         /* sow_h_save_elems(T, r_live) elements           */
+  const void* dy;       /* backward: upstream gradient [T, d_out]         */
+  void* dx;             /* [T, d_in]                                      */
+  void* dA;
+  void* dB;
+  void* dbias;          /* or NULL                                        */
+  int64_t T;
+  int32_t d_in, d_out, r_live, r_acc, acc_kind;
+  float scale, grad_beta;
+  void* workspace;      /* this layer's own workspace (sow_workspace_bytes) */
+  size_t workspace_bytes;
+} sow_layer_args;
+int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stream);
+/* phases as in sow_backward_ex; the phases run in order DATA (all layers), WEIGHTS_PARTIAL (all), WEIGHTS_REDUCE (all). */
+int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phases, void* stream);
+
 /* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
  * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call
  * sites: accumulate() sow.py:131-140 (W_acc += scale * A @ B, Q @ R), prepare.py:135, tt.py:213-237. */

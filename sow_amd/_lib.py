@@ -18,6 +18,17 @@ ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2
 H_COLS = 64
 BWD_DATA, BWD_WEIGHTS, BWD_WEIGHTS_PARTIAL, BWD_WEIGHTS_REDUCE = 1, 2, 4, 8
 
+
+
+class LayerArgs(ctypes.Structure):
+    """sow_layer_args of include/sow_amd.h (field order and types one to one)."""
+    _fields_ = [("x", c_void_p), ("A", c_void_p), ("B", c_void_p), ("acc_down", c_void_p), ("acc_up", c_void_p),
+                ("bias", c_void_p), ("y", c_void_p), ("h_save", c_void_p), ("dy", c_void_p), ("dx", c_void_p),
+                ("dA", c_void_p), ("dB", c_void_p), ("dbias", c_void_p), ("T", c_int64), ("d_in", ctypes.c_int32),
+                ("d_out", ctypes.c_int32), ("r_live", ctypes.c_int32), ("r_acc", ctypes.c_int32), ("acc_kind", ctypes.c_int32),
+                ("scale", c_float), ("grad_beta", c_float), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 # name -> (restype, argtypes); mirrors include/sow_amd.h one to one
 SIGNATURES = {
     "sow_version": (c_int, []),
@@ -33,6 +44,8 @@ SIGNATURES = {
                                                  c_void_p, c_size_t, c_void_p]),
     "sow_backward_ex": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                     c_void_p, c_size_t, c_int, c_void_p]),
+    "sow_forward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_void_p]),
+    "sow_backward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p]),
     "sow_reduce_desc_bytes": (c_size_t, []),
     "sow_backward_reduce_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_void_p, c_size_t, c_void_p, c_void_p]),

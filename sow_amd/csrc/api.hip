@@ -484,6 +484,155 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
                          scale, grad_beta, dtype, workspace, workspace_bytes, SOW_BWD_DATA | SOW_BWD_WEIGHTS, stream);
 }
 
+// ---- grouped entry points ------------------------------------------------------------------------------------
+// A group is n INDEPENDENT SoWLinear calls (e.g. q / k / v of one attention block, gate / up of one MLP).  Layers that
+// take the plain bf16 streaming kernels (no accumulator, r <= 64, T / 64 > SHORT_NTB) share launches, C2_MAXG /
+// TN_MAXG at a time; every other layer is forwarded to the single-layer entry point.  Results are bit-identical to n
+// separate calls: the shared grid runs each layer's own workgroups unchanged.
+static bool group_chain_params(const sow_layer_args& L, bool bwd, int dtype, const WsPlan& w, ChainParams* out) {
+  if (dtype != SOW_BF16 || L.acc_kind != SOW_ACC_NONE || L.r_live > 64 || sw_on(SW_NO_GROUPED) || sw_on(SW_FORCE_CHAIN_V1))
+    return false;
+  if (ceil_div(L.T, 64) <= SHORT_NTB) return false;   // short inputs: K / column split, single-layer path
+  ChainParams p{};
+  if (!bwd) {
+    p.X = L.x, p.Y = L.y, p.Hsave = L.h_save, p.bias = L.bias;
+    p.M = L.T, p.ldx = L.d_in, p.ldy = L.d_out, p.D1 = L.d_in, p.D2 = L.d_out;
+    p.F1b = L.A, p.ldf1b = L.r_live, p.F2b = L.B, p.ldf2b = L.d_out, p.rb = L.r_live;
+  } else {
+    p.X = L.dy, p.Y = L.dx, p.Hsave = ws_base(L.workspace) + w.off_dh, p.bias = nullptr;
+    p.M = L.T, p.ldx = L.d_out, p.ldy = L.d_in, p.D1 = L.d_out, p.D2 = L.d_in;
+    p.F1b = L.B, p.ldf1b = L.d_out, p.F2b = L.A, p.ldf2b = L.r_live, p.rb = L.r_live;
+  }
+  p.scale = L.scale, p.beta = 0.f;
+  if (!chain2_supported(p, dtype)) return false;
+  // the alignment conditions launch_chain2 would reject (it then falls back inside launch_chain)
+  const void* Bp = bwd ? p.F1b : p.F2b;
+  const int64_t ldB = bwd ? p.ldf1b : p.ldf2b;
+  const void* Ap = bwd ? p.F2b : p.F1b;
+  if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 8 || (reinterpret_cast<uintptr_t>(Ap) & 3)) return false;
+  *out = p;
+  return true;
+}
+
+static int check_layer(const sow_layer_args& L, bool bwd) {
+  if (L.T < 0 || L.d_in <= 0 || L.d_out <= 0 || L.r_live <= 0) return SOW_ERR_SHAPE;
+  if (L.T == 0) return SOW_OK;
+  if (!L.x || !L.A || !L.B) return SOW_ERR_NULL;
+  if (!bwd && !L.y) return SOW_ERR_NULL;
+  if (bwd && (!L.dy || !L.h_save || !L.dx || !L.dA || !L.dB || !L.workspace)) return SOW_ERR_NULL;
+  if (L.acc_kind != SOW_ACC_NONE && !L.acc_down) return SOW_ERR_NULL;
+  return SOW_OK;
+}
+
+int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!layers) return SOW_ERR_NULL;
+  ChainParams batch[C2_MAXG];
+  int nb = 0, rc;
+  for (int i = 0; i < n; ++i) {
+    const sow_layer_args& L = layers[i];
+    if ((rc = check_layer(L, false))) return rc;
+    if (L.T == 0) continue;
+    const WsPlan w{};
+    if (L.h_save && group_chain_params(L, false, dtype, w, &batch[nb])) {
+      if (++nb == C2_MAXG) {
+        if ((rc = launch_chain2_group(batch, nb, false, stream))) return rc;
+        nb = 0;
+      }
+      continue;
+    }
+    rc = sow_forward(L.x, L.A, L.B, L.acc_down, L.acc_up, L.bias, L.y, L.h_save, L.T, L.d_in, L.d_out, L.r_live, L.r_acc,
+                     L.acc_kind, L.scale, dtype, L.workspace, L.workspace_bytes, stream_);
+    if (rc) return rc;
+  }
+  return nb ? launch_chain2_group(batch, nb, false, stream) : SOW_OK;
+}
+
+int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phases, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool do_data = (phases & SOW_BWD_DATA) != 0;
+  const bool do_partial = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_PARTIAL)) != 0;
+  const bool do_reduce = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_REDUCE)) != 0;
+  if (!do_data && !do_partial && !do_reduce) return SOW_ERR_SHAPE;
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!layers) return SOW_ERR_NULL;
+  int rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = check_layer(layers[i], true))) return rc;
+  auto single = [&](const sow_layer_args& L, int ph) {
+    return sow_backward_ex(L.dy, L.x, L.h_save, L.A, L.B, L.acc_down, L.acc_up, L.dx, L.dA, L.dB, L.dbias, L.T, L.d_in, L.d_out,
+                           L.r_live, L.r_acc, L.acc_kind, L.scale, L.grad_beta, dtype, L.workspace, L.workspace_bytes, ph,
+                           stream_);
+  };
+  auto plan = [&](const sow_layer_args& L) {
+    return plan_ws(L.T, L.d_in, L.d_out, L.r_live, L.acc_kind == SOW_ACC_LOWRANK ? L.r_acc : 0, L.acc_kind, dtype);
+  };
+  if (do_data) {
+    ChainParams batch[C2_MAXG];
+    int nb = 0;
+    for (int i = 0; i < n; ++i) {
+      const sow_layer_args& L = layers[i];
+      if (L.T == 0) {
+        if ((rc = single(L, SOW_BWD_DATA | (phases & ~SOW_BWD_DATA)))) return rc;   // empty batch: everything at once
+        continue;
+      }
+      const WsPlan w = plan(L);
+      if (L.workspace_bytes < w.total + 255) return SOW_ERR_WORKSPACE;
+      if (group_chain_params(L, true, dtype, w, &batch[nb])) {
+        if (++nb == C2_MAXG) {
+          if ((rc = launch_chain2_group(batch, nb, true, stream))) return rc;
+          nb = 0;
+        }
+      } else if ((rc = single(L, SOW_BWD_DATA)))
+        return rc;
+    }
+    if (nb && (rc = launch_chain2_group(batch, nb, true, stream))) return rc;
+  }
+  if (do_partial) {
+    TnParams batch[TN_MAXG];
+    int nb = 0;
+    for (int i = 0; i < n; ++i) {
+      const sow_layer_args& L = layers[i];
+      if (L.T == 0) {
+        if (!do_data && (rc = single(L, phases))) return rc;
+        continue;
+      }
+      const WsPlan w = plan(L);
+      if (L.workspace_bytes < w.total + 255) return SOW_ERR_WORKSPACE;
+      bool grouped = false;
+      if (L.r_live <= 64 && !sw_on(SW_NO_GROUPED)) {
+        char* ws = ws_base(L.workspace);
+        TnParams tp{};
+        tp.njobs = 2, tp.T = L.T, tp.ns = w.ns, tp.slab_len = w.slab_len;
+        const bool ones_ok = L.dbias && L.r_live <= 63;
+        const int vx = (L.d_in % 2 == 0 && al4p(L.x)) ? 1 : 0, vy = (L.d_out % 2 == 0 && al4p(L.dy)) ? 1 : 0;
+        tp.job[0] = TnJob{L.x, ws + w.off_dh, (float*)(ws + w.off_p0), (int64_t)L.d_in, L.d_in, -1, (L.d_in + 63) / 64, vx, 1};
+        tp.job[1] = TnJob{L.dy, L.h_save, (float*)(ws + w.off_p1), (int64_t)L.d_out, L.d_out, ones_ok ? 63 : -1,
+                          (L.d_out + 63) / 64, vy, 1};
+        if (tn_group_supported(tp, dtype)) {
+          batch[nb] = tp;
+          grouped = true;
+          if (++nb == TN_MAXG) {
+            if ((rc = launch_tn_group(batch, nb, stream))) return rc;
+            nb = 0;
+          }
+        }
+      }
+      if (!grouped && (rc = single(L, SOW_BWD_WEIGHTS_PARTIAL))) return rc;
+    }
+    if (nb && (rc = launch_tn_group(batch, nb, stream))) return rc;
+  }
+  if (do_reduce)
+    for (int i = 0; i < n; ++i)
+      if (layers[i].T != 0 && (rc = single(layers[i], SOW_BWD_WEIGHTS_REDUCE))) return rc;
+  return SOW_OK;
+}
+
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
              const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream) {
   if (!trans_a) return gemm_auto(A, lda, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);

@@ -62,15 +62,28 @@ template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
 // =================================================================================================
 // BWD = false: forward  (F1 = A [D1, r] rows = k, F2 = B [r, D2] rows = k  -> transposed reads)
 // BWD = true : backward (F1 = B [r, D1] rows = rank, F2 = A [D2, r] rows = n -> b128 / b64 reads)
-template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kernel(const ChainParams p) {
+//
+// Grouped launch: the grid is the concatenation of the grids of up to C2_MAXG independent layers (same direction; shapes
+// may differ) -- e.g. the q / k / v projections of an attention block, or gate / up of an MLP.  A launch costs ~8 us of
+// ramp, first-DMA round trip, hand-off and write drain whatever its size (tools/chain_sweep.py: t = 8.6 us + bytes /
+// 5.1 TB/s), so three 512-workgroup layers in one 1536-workgroup grid pay it once; later rounds start while earlier
+// workgroups drain.  Every workgroup runs exactly the single-layer code on its own layer's parameter block, so the
+// results are bit-identical to separate launches.
+template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kernel(const ChainGroup grp) {
   constexpr bool TR = !BWD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int layer = 0;
+#pragma unroll
+  for (int i = 1; i < C2_MAXG; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.start[i]) layer = i;
+  const ChainParams& p = grp.p[layer];
+  const int bid = (int)blockIdx.x - grp.start[layer];
   // short-T split (kernels.hpp): workgroup = (token block, split); a split owns a range of phase-1 stages OR of
   // phase-2 slices.  Without a split every workgroup owns all of both.
-  const int tb = p.ntb > 0 ? (int)blockIdx.x % p.ntb : (int)blockIdx.x;
-  const int split = p.ntb > 0 ? (int)blockIdx.x / p.ntb : 0;
+  const int tb = p.ntb > 0 ? bid % p.ntb : bid;
+  const int split = p.ntb > 0 ? bid / p.ntb : 0;
   const int64_t m0 = (int64_t)tb * C2_BM;
   const int D1 = p.D1, D2 = p.D2, rb = p.rb;
   const int nst_all = (D1 + 63) / 64, nsl_all = (D2 + 63) / 64;
@@ -166,13 +179,13 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
   }
 
   // -------------------------------------------------------------------- compute waves
-  if (p.pad_dst && (int)blockIdx.x * 64 < p.pad_rows) {
+  if (p.pad_dst && bid * 64 < p.pad_rows) {
     // side job (first ceil(rows / 64) workgroups): two 8-column groups per thread, plain guarded loads
     const bf16_t* src = (const bf16_t*)p.pad_src;
     bf16_t* dst = (bf16_t*)p.pad_dst;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int idx = t + 256 * it, row = blockIdx.x * 64 + (idx >> 3), c0 = (idx & 7) * 8;
+      const int idx = t + 256 * it, row = bid * 64 + (idx >> 3), c0 = (idx & 7) * 8;
       if (row < p.pad_rows) {
         u32x4 v;
         bf16_t* e = (bf16_t*)&v;
@@ -525,28 +538,47 @@ int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, i
   return SOW_OK;
 }
 
-int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream) {
+static int chain2_grid(const ChainParams& p) {
   // B is DMA'd in aligned 16-byte pieces along its rows; A must be contiguous [rows, r] and 4-byte aligned
-  const void* Bp = bwd ? p.F1b : p.F2b;
-  const int64_t ldB = bwd ? p.ldf1b : p.ldf2b;
-  const void* Ap = bwd ? p.F2b : p.F1b;
-  const int64_t ldA = bwd ? p.ldf2b : p.ldf1b;
-  if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 8 || (reinterpret_cast<uintptr_t>(Ap) & 3) || ldA != p.rb)
-    return SOW_ERR_ALIGN;
-  int grid = ceil_div(p.M, C2_BM);
   if (p.ntb > 0) {
     const int nsplit = p.st_per > 0 ? ceil_div((p.D1 + 63) / 64, p.st_per) : ceil_div((p.D2 + 63) / 64, p.sl_per);
-    grid = p.ntb * nsplit;
+    return p.ntb * nsplit;
   }
+  return ceil_div(p.M, C2_BM);
+}
+
+int launch_chain2_group(const ChainParams* ps, int n, bool bwd, hipStream_t stream) {
+  if (n <= 0) return SOW_OK;
+  if (n > C2_MAXG) return SOW_ERR_SHAPE;
+  ChainGroup g{};
+  g.n = n;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const ChainParams& p = ps[i];
+    const void* Bp = bwd ? p.F1b : p.F2b;
+    const int64_t ldB = bwd ? p.ldf1b : p.ldf2b;
+    const void* Ap = bwd ? p.F2b : p.F1b;
+    const int64_t ldA = bwd ? p.ldf2b : p.ldf1b;
+    if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 8 || (reinterpret_cast<uintptr_t>(Ap) & 3) || ldA != p.rb)
+      return SOW_ERR_ALIGN;
+    g.p[i] = p;
+    g.start[i] = (int)total;
+    total += chain2_grid(p);
+  }
+  for (int i = n; i <= C2_MAXG; ++i) g.start[i] = (int)total;
+  if (total <= 0) return SOW_OK;
+  if (total > 0x7fffffff) return SOW_ERR_SHAPE;
   if (bwd) {
     SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<true>);
-    hipLaunchKernelGGL(chain2_kernel<true>, dim3(grid), dim3(C2_THREADS), C2_LDS, stream, p);
+    hipLaunchKernelGGL(chain2_kernel<true>, dim3((unsigned)total), dim3(C2_THREADS), C2_LDS, stream, g);
   } else {
     SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<false>);
-    hipLaunchKernelGGL(chain2_kernel<false>, dim3(grid), dim3(C2_THREADS), C2_LDS, stream, p);
+    hipLaunchKernelGGL(chain2_kernel<false>, dim3((unsigned)total), dim3(C2_THREADS), C2_LDS, stream, g);
   }
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }
+
+int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream) { return launch_chain2_group(&p, 1, bwd, stream); }
 
 }  // namespace sow

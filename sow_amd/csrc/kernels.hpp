@@ -30,8 +30,16 @@ struct ChainParams {
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
+constexpr int C2_MAXG = 4;   // layers per grouped launch
+struct ChainGroup {
+  ChainParams p[C2_MAXG];
+  int start[C2_MAXG + 1];    // first workgroup of layer i; start[n..] = grid size
+  int n;
+};
 bool chain2_supported(const ChainParams& p, int dtype);
 int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream);
+// one grid for n <= C2_MAXG independent layers of the same direction (each one chain2_supported)
+int launch_chain2_group(const ChainParams* ps, int n, bool bwd, hipStream_t stream);
 int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, int rb, float scale, int dtype,
                     hipStream_t stream);
 // chain2f.hip (fp32 streaming version)
@@ -76,6 +84,14 @@ struct ReduceParams {
 int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len);
 size_t tn_partial_bytes(int ns, int D);
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
+constexpr int TN_MAXG = 4;   // layers per grouped launch of the wide bf16 kernel
+struct TnGroup {
+  TnParams p[TN_MAXG];
+  int start[TN_MAXG + 1];
+  int n;
+};
+bool tn_group_supported(const TnParams& p, int dtype);
+int launch_tn_group(const TnParams* ps, int n, hipStream_t stream);
 int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);
 int launch_tn_reduce_batch(const ReduceParams* descs, const int* starts, int n, int total_blocks, int dtype, hipStream_t stream);
 // gemm.hip

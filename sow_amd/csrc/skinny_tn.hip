@@ -391,11 +391,18 @@ __device__ __forceinline__ void tnw_wait_stages(int newer) {   // 6 DMA instruct
   }
 }
 
-__global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(const TnParams p) {
+// Grouped launch (TnGroup): the grids of up to TN_MAXG layers back to back; every workgroup runs the single-layer code
+// on its layer's parameters (bit-identical partials), the ~8 us of launch ramp and drain are paid once per group.
+__global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(const TnGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  int b = blockIdx.x, jid = 0;
+  int layer = 0;
+#pragma unroll
+  for (int i = 1; i < TN_MAXG; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.start[i]) layer = i;
+  const TnParams& p = grp.p[layer];
+  int b = (int)blockIdx.x - grp.start[layer], jid = 0;
   const int ncg2_0 = (p.job[0].ncg + 1) / 2;
   if (p.njobs > 1 && b >= ncg2_0 * p.ns) {
     b -= ncg2_0 * p.ns;
@@ -800,23 +807,54 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
 
 size_t tn_partial_bytes(int ns, int D) { return (size_t)ns * ((D + 63) / 64 * 64) * 64 * sizeof(float); }
 
+static bool tn_wide_ok(const TnParams& p) {
+  bool dma = p.slab_len % 16 == 0;
+  for (int j = 0; j < p.njobs; ++j) {
+    const TnJob& J = p.job[j];
+    dma = dma && J.D % 8 == 0 && J.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
+          (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
+  }
+  return dma;
+}
+static int tn_wide_blocks(const TnParams& p) {
+  int blocks2 = 0;   // two 64-column groups per block
+  for (int j = 0; j < p.njobs; ++j) blocks2 += (p.job[j].ncg + 1) / 2 * p.ns;
+  return blocks2;
+}
+
+bool tn_group_supported(const TnParams& p, int dtype) {
+  return dtype == SOW_BF16 && tn_wide_ok(p) && !sw_on(SW_TN_NARROW) && tn_wide_blocks(p) > 0;
+}
+
+int launch_tn_group(const TnParams* ps, int n, hipStream_t stream) {
+  if (n <= 0) return SOW_OK;
+  if (n > TN_MAXG) return SOW_ERR_SHAPE;
+  TnGroup g{};
+  g.n = n;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = ps[i];
+    g.start[i] = (int)total;
+    total += tn_wide_blocks(ps[i]);
+  }
+  for (int i = n; i <= TN_MAXG; ++i) g.start[i] = (int)total;
+  if (total <= 0) return SOW_OK;
+  if (total > 0x7fffffff) return SOW_ERR_SHAPE;
+  constexpr int LDS = TNW_WAVES * TNW_DEPTH * TNW_STAGE_BYTES;  // 144 KiB (rings; reused by the cross-wave sum)
+  SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
+  hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3((unsigned)total), dim3(64 * TNW_WAVES), LDS, stream, g);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
   int blocks = 0;
   for (int j = 0; j < p.njobs; ++j) blocks += p.job[j].ncg * p.ns;
   if (blocks == 0) return SOW_OK;
   if (dtype == SOW_BF16) {
-    bool dma = p.slab_len % 16 == 0;
-    for (int j = 0; j < p.njobs; ++j) {
-      const TnJob& J = p.job[j];
-      dma = dma && J.D % 8 == 0 && J.ldm % 8 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
-            (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
-    }
+    const bool dma = tn_wide_ok(p);
     if (dma && !sw_on(SW_TN_NARROW)) {
-      constexpr int LDS = TNW_WAVES * TNW_DEPTH * TNW_STAGE_BYTES;  // 144 KiB (rings; reused by the cross-wave sum)
-      SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
-      int blocks2 = 0;   // two 64-column groups per block
-      for (int j = 0; j < p.njobs; ++j) blocks2 += (p.job[j].ncg + 1) / 2 * p.ns;
-      hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3(blocks2), dim3(64 * TNW_WAVES), LDS, stream, p);
+      return launch_tn_group(&p, 1, stream);
     } else if (dma) {
       constexpr int LDS = 4 * TN_DEPTH * TN_STAGE_BYTES;  // 64 KiB (rings; reused by the cross-wave sum)
       SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_kernel);

@@ -69,6 +69,7 @@ class _GradSink:
         self.bucket._reducer.add(x2, B, out, 1.0, self.ws, acc_down, acc_up)
         self.bucket._sinks_pending.append(self)
         self.pending = True
+        self.bucket._layer_done()
         return dx
 
 
@@ -101,18 +102,35 @@ class FactorBucket:
         self._reducer = None
         self._sinks_pending: list = []
         self._off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        self._n_attached = 0
+        self._arrived = 0
+        self._auto = False
+        self._auto_group = None
+        self._average = True
+        self._group = None
 
     # ------------------------------------------------------------------ deferred weight-gradient reduction
     def grad_ptr(self, p) -> int:
         return self.flat_grad.data_ptr() + self._off_of[id(p)] * self.flat_grad.element_size()
 
-    def attach(self, model: nn.Module) -> int:
+    def attach(self, model: nn.Module, auto_all_reduce: bool = False, group=None) -> int:
         """Let the SoWLinear layers of `model` (n_iter = 1, no bias) write their weight gradients straight into the
         flat buffer and defer the final reduction to finalize(): one launch per step instead of one per layer, and no
         per-parameter AccumulateGrad.  Gradients ACCUMULATE (zero_grad() between steps); call finalize() after
         backward, before the gradients are read (all_reduce_async() and FactorAdamW.step() do).  Returns the number of
-        layers attached; layers with a bias or n_iter > 1 keep the ordinary autograd path."""
+        layers attached; layers with a bias or n_iter > 1 keep the ordinary autograd path.
+
+        auto_all_reduce: issue the bucket's single all-reduce FROM BACKWARD, as soon as the last attached layer has
+        queued its partial sums (the first SoW layer of the model: what is left of backward -- embedding gradients, DDP's
+        own buckets for the non-factor parameters -- overlaps the collective); the step then only calls wait().
+
+        Autograd returns None for attached factors, so DistributedDataParallel must not manage them: attach BEFORE
+        wrapping and call exclude_from_ddp(model) (a model that is already DDP-wrapped is refused)."""
         from . import ops
+        if isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            raise RuntimeError("FactorBucket.attach: attach to the bare model and call exclude_from_ddp(model) BEFORE wrapping "
+                               "it in DistributedDataParallel (attached factors get no autograd gradient, DDP's reducer "
+                               "would wait for them forever)")
         if self._reducer is None:
             self._reducer = ops.DeferredReduce()
         mine = {id(p) for p in self.params}
@@ -123,7 +141,23 @@ class FactorBucket:
                 if id(pA) in mine and id(pB) in mine:
                     m._grad_sink = _GradSink(self, pA, pB)
                     n += 1
+        self._n_attached = n
+        self._auto, self._auto_group = bool(auto_all_reduce), group
         return n
+
+    def exclude_from_ddp(self, model: nn.Module) -> List[str]:
+        """Put the bucket's parameters on DistributedDataParallel's ignore list for `model` (call before wrapping):
+        DDP then reduces only the non-factor parameters (embeddings, norms, lm_head) in its own buckets while the
+        factors travel in this bucket's ONE all-reduce."""
+        mine = {id(p) for p in self.params}
+        names = [n for n, p in model.named_parameters() if id(p) in mine]
+        torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, names)
+        return names
+
+    def _layer_done(self) -> None:
+        self._arrived += 1
+        if self._auto and self._n_attached and self._arrived == self._n_attached:
+            self.all_reduce_async(group=self._auto_group)
 
     def finalize(self) -> None:
         """Sum the pending slab partials of every attached layer (no-op when nothing is pending)."""
@@ -176,8 +210,14 @@ class FactorBucket:
     def wait(self) -> float:
         """Block the current stream on the collective; returns the scale the optimizer must apply to
         the summed gradient (1/world for averaging -- folded into FactorAdamW.step(grad_scale))."""
+        self._arrived = 0
         if self._work is None:
-            return 1.0
+            if self._auto and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._auto_group) > 1:
+                # not every attached layer ran backward this step (unused branch): reduce now
+                self.all_reduce_async(group=self._auto_group)
+            if self._work is None:
+                self.finalize()
+                return 1.0
         self._work.wait()
         if self.flat_grad.is_cuda and self._comm_stream is not None:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)

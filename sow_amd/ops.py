@@ -181,6 +181,62 @@ def sow_backward(dy2: torch.Tensor, x2: torch.Tensor, h: torch.Tensor, A: torch.
     return dx, dA, dB, dbias
 
 
+class LayerCall:
+    """Arguments of one SoWLinear forward / backward inside a grouped call (include/sow_amd.h: sow_layer_args).  Static
+    training buffers: build once, reuse every step.  `out` = (dA, dB, dbias) gradient buffers, `workspace` this layer's
+    own workspace (workspace_bytes())."""
+
+    def __init__(self, x2, A, B, *, acc_down=None, acc_up=None, bias=None, scale=1.0, y=None, h=None, dy2=None, dx=None,
+                 out=None, grad_beta=0.0, workspace=None):
+        dev = _need_gpu(x2, A, B, bias, y, h, dy2, dx, workspace)
+        self.dtype = _dt(x2)
+        T, d_in = x2.shape
+        r, d_out = B.shape
+        kind = acc_kind(acc_down, acc_up)
+        for name, t in (("x", x2), ("A", A), ("B", B), ("bias", bias), ("y", y), ("dy", dy2), ("dx", dx)):
+            if t is not None and (not t.is_contiguous() or t.dtype != x2.dtype):
+                raise ValueError(f"sow_amd.LayerCall: {name} must be contiguous and of the input dtype")
+        if A.shape != (d_in, r):
+            raise ValueError("sow_amd.LayerCall: factor shapes do not match the input")
+        self.device, self.kind = dev, kind
+        self.y = y if y is not None else torch.empty((T, d_out), dtype=x2.dtype, device=dev)
+        self.h = h if h is not None else torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)
+        self.dx = dx
+        nws = workspace_bytes(T, d_in, d_out, r, acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0, kind, x2.dtype)
+        self.workspace = workspace if workspace is not None else _ws(nws, dev)
+        if self.workspace.numel() < nws:
+            raise ValueError("sow_amd.LayerCall: workspace too small")
+        dA, dB, dbias = out if out is not None else (None, None, None)
+        self._keep = (x2, A, B, acc_down, acc_up, bias, dy2, dA, dB, dbias)     # the struct holds raw pointers
+        self.args = _lib.LayerArgs(
+            x=_ptr(x2), A=_ptr(A), B=_ptr(B), acc_down=_ptr(acc_down) if kind != _lib.ACC_NONE else None,
+            acc_up=_ptr(acc_up) if kind == _lib.ACC_LOWRANK else None, bias=_ptr(bias), y=_ptr(self.y), h_save=_ptr(self.h),
+            dy=_ptr(dy2), dx=_ptr(dx), dA=_ptr(dA), dB=_ptr(dB), dbias=_ptr(dbias), T=T, d_in=d_in, d_out=d_out, r_live=r,
+            r_acc=acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0, acc_kind=kind, scale=float(scale),
+            grad_beta=float(grad_beta), workspace=_ptr(self.workspace), workspace_bytes=self.workspace.numel())
+
+
+class LayerGroup:
+    """n independent layer calls issued through sow_forward_group / sow_backward_group: layers on the bf16 streaming
+    kernels share launches (q / k / v; gate / up).  Results are bit-identical to n single calls."""
+
+    def __init__(self, calls: Sequence[LayerCall]):
+        if not calls:
+            raise ValueError("empty group")
+        if len({c.dtype for c in calls}) != 1 or len({c.device for c in calls}) != 1:
+            raise ValueError("sow_amd.LayerGroup: all layers must share dtype and device")
+        self.calls = list(calls)
+        self.arr = (_lib.LayerArgs * len(calls))(*[c.args for c in calls])
+        self.dtype, self.device = calls[0].dtype, calls[0].device
+
+    def forward(self) -> None:
+        _launch(self.device, "sow_forward_group", _lib.load().sow_forward_group, self.arr, len(self.calls), self.dtype)
+
+    def backward(self, phases: int = _lib.BWD_DATA | _lib.BWD_WEIGHTS) -> None:
+        _launch(self.device, "sow_backward_group", _lib.load().sow_backward_group, self.arr, len(self.calls), self.dtype,
+                int(phases))
+
+
 class DeferredReduce:
     """The weight-gradient reductions of many layers in one launch (include/sow_amd.h: sow_reduce_batch).
 

@@ -142,6 +142,10 @@ class FactorAdamW:
 
     def step(self, grad_scale: float = 1.0):
         self.bucket.finalize()   # pending deferred weight-gradient reductions (FactorBucket.attach)
+        for p, o in zip(self.bucket.params, self.bucket.offsets):
+            if p.data_ptr() != self.bucket.flat_param.data_ptr() + o * self.bucket.flat_param.element_size():
+                raise RuntimeError("FactorAdamW.step: a factor no longer lives in the flat buffer (SoWLinear.accumulate() "
+                                   "rebinds .data) -- call bucket.rebind() after accumulate(); sow_amd.accumulate(model) does")
         self.step_count += 1
         ops.adamw_flat_(self.bucket.flat_param, self.bucket.flat_grad, self.exp_avg, self.exp_avg_sq, lr=self.lr,
                         betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, step=self.step_count,
@@ -151,3 +155,33 @@ class FactorAdamW:
         """reset_optimizer for the factor group (training_utils.py:257-277) as one launch."""
         ops.zero_([self.exp_avg, self.exp_avg_sq])
         self.step_count = 0
+
+    # ---- checkpoint / scheduler surface (simple_train.py:182, 537-563 save and restore optimizer + scheduler state)
+    @property
+    def param_groups(self):
+        """One group, torch.optim style: LR schedulers read and write group["lr"] (kept in sync with self.lr)."""
+        if not hasattr(self, "_group"):
+            self._group = {"params": self.bucket.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
+                           "weight_decay": self.weight_decay}
+        else:
+            self.lr, self.betas = self._group["lr"], self._group["betas"]
+            self.eps, self.weight_decay = self._group["eps"], self._group["weight_decay"]
+        return [self._group]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.bucket.zero_grad()
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "numel": self.bucket.padded_numel}
+
+    def load_state_dict(self, sd):
+        if int(sd["numel"]) != self.bucket.padded_numel:
+            raise ValueError("FactorAdamW.load_state_dict: the checkpoint belongs to a different factor layout")
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lr, self.betas, self.eps, self.weight_decay = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"]), float(sd["weight_decay"])
+        if hasattr(self, "_group"):
+            self._group.update(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)

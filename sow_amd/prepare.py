@@ -143,6 +143,18 @@ def accumulate(model):
     current stream: 56 layers take ~7 QR latencies instead of 56.  Host order is unchanged, so the Gaussian
     re-initialisation draws come out of the generator exactly as in the sequential loop."""
     mods = [m for _, m in model.named_modules() if isinstance(m, SoWLinear)]
+    # layers attached to a FactorBucket (sow_amd/dp.py): pending partial sums belong to the OLD factors -- reduce them
+    # first; afterwards the rebound .data tensors are copied back into the flat buffer so the fused optimizer and the
+    # all-reduce keep seeing them
+    buckets = {id(s.bucket): s.bucket for s in (getattr(m, "_grad_sink", None) for m in mods) if s is not None}
+    for b in buckets.values():
+        b.finalize()
+    _accumulate_layers(mods)
+    for b in buckets.values():
+        b.rebind()
+
+
+def _accumulate_layers(mods):
     dev = mods[0].downscale_weights[0].device if mods else None
     if len(mods) < 2 or dev is None or dev.type != "cuda":
         for m in mods:

@@ -354,3 +354,54 @@ def test_tt_newton_and_reciprocal_vs_reference():
     rec = TensorTrain.from_cores([g[f"recip_in{i}"].to(DEV) for i in range(3)]).reciprocal()
     for i in range(3):
         assert rel_err(rec.cores[i].cpu(), g[f"recip_out{i}"]) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# grouped C-ABI calls (sow_forward_group / sow_backward_group)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["qkv", "gate_up", "mixed"])
+def test_grouped_calls_are_bit_identical_to_single_calls(case):
+    """{q, k, v} / {gate, up} of a decoder block in ONE grid per kernel: outputs, saved h, dX, dA, dB bit-identical to the
+    per-layer calls (every workgroup runs the single-layer code on its own layer).  `mixed`: an eligible layer next to a
+    dense-accumulator layer, a short-T layer and an fp32-only shape -- those are forwarded to the single-layer path."""
+    from sow_amd import _lib, ops
+    T = 16400   # ragged last token block; > 8192 so the streaming kernels are not split
+    if case == "qkv":
+        specs = [(T, 512, 512, 50, False)] * 3
+    elif case == "gate_up":
+        specs = [(T, 512, 1376, 50, False), (T, 512, 1376, 50, False)]
+    else:
+        specs = [(T, 512, 512, 50, False), (T, 512, 512, 50, True), (4096, 512, 1376, 50, False), (T, 264, 72, 34, False),
+                 (T, 1376, 512, 50, False)]
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    calls, singles = [], []
+    for (t, di, do, r, dense) in specs:
+        x = torch.randn(t, di, generator=gen, device=DEV).bfloat16()
+        dy = torch.randn(t, do, generator=gen, device=DEV).bfloat16()
+        A = (torch.randn(di, r, generator=gen, device=DEV) * 0.05).bfloat16()
+        B = (torch.randn(r, do, generator=gen, device=DEV) * 0.05).bfloat16()
+        W = (torch.randn(di, do, generator=gen, device=DEV) * 0.02).bfloat16() if dense else None
+        dA, dB = torch.zeros_like(A), torch.zeros_like(B)
+        dx = torch.empty_like(x)
+        calls.append(ops.LayerCall(x, A, B, acc_down=W, scale=0.75, dy2=dy, dx=dx, out=(dA, dB, None), grad_beta=0.0))
+        y1, h1 = ops.sow_forward(x, A, B, W, None, None, 0.75)
+        dx1, dA1, dB1, _ = ops.sow_backward(dy, x, h1, A, B, W, None, 0.75, False)
+        singles.append((y1, h1, dx1, dA1, dB1))
+    grp = ops.LayerGroup(calls)
+    grp.forward()
+    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    torch.cuda.synchronize()
+    for c, (y1, h1, dx1, dA1, dB1) in zip(calls, singles):
+        r = c.args.r_live
+        hv, h1v = c.h.view(-1, 64), h1.view(-1, 64)
+        assert torch.equal(c.y, y1) and torch.equal(hv[:, :r], h1v[:, :r]) and torch.equal(hv[:, 63], h1v[:, 63])
+        assert torch.equal(c.dx, dx1)
+        assert torch.equal(c._keep[7], dA1) and torch.equal(c._keep[8], dB1)
+    # the same with the grouping switched off (layer-by-layer through the group entry point)
+    with _lib.switch(NO_GROUPED=1):
+        for c in calls:
+            c.y.zero_()
+        grp.forward()
+        grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    for c, (y1, _, dx1, dA1, _) in zip(calls, singles):
+        assert torch.equal(c.y, y1) and torch.equal(c.dx, dx1) and torch.equal(c._keep[7], dA1)

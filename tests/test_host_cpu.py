@@ -295,3 +295,119 @@ def test_utils_helpers_off_the_hot_path():
     assert torch.equal(r, r.triu()) and bool((r.diagonal() > 0).all())
     assert torch.linalg.matrix_rank(generate_rank_k((6, 7), 2)) == 2
     assert perturbe_random(torch.zeros(3, 3)).abs().max() > 0
+
+
+_DP_PROTOCOL_WORKER = r'''
+import copy, os, sys, torch, torch.distributed as dist
+root = sys.argv[3]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+rank, world = int(sys.argv[1]), 2
+dist.init_process_group("gloo", init_method="file://" + sys.argv[2], rank=rank, world_size=world)
+import torch.nn as nn
+from oracle_backend import OracleSoWLinear           # CPU arithmetic of the layer: the oracle (test infrastructure)
+from sow_amd import FactorBucket
+from sow_amd.optimizer import FactorAdamW
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.l1 = OracleSoWLinear(12, 10, False, 4, 0.5, "normal")
+        self.l2 = OracleSoWLinear(10, 6, False, 4, 0.5, "normal")
+        self.head = nn.Linear(6, 3)
+    def forward(self, x):
+        return self.head(self.l2(torch.tanh(self.l1(x))))
+
+torch.manual_seed(0)
+net = Net()
+for m in (net.l1, net.l2):
+    nn.init.normal_(m.downscale_weights[0], std=0.3); nn.init.normal_(m.upscale_weights[0], std=0.3)
+ref = copy.deepcopy(net)                                 # single-process twin, sees the concatenated batch
+X = torch.randn(8, 12)
+factors = [net.l1.downscale_weights[0], net.l1.upscale_weights[0], net.l2.downscale_weights[0], net.l2.upscale_weights[0]]
+bucket = FactorBucket(factors)                           # CPU-resident flat buffers
+ignored = bucket.exclude_from_ddp(net)
+assert sorted(ignored) == ["l1.downscale_weights.0", "l1.upscale_weights.0", "l2.downscale_weights.0", "l2.upscale_weights.0"]
+ddp = nn.parallel.DistributedDataParallel(net)           # reduces head.* only
+bucket._n_attached, bucket._auto = 2, True              # what attach(model, auto_all_reduce=True) sets on the GPU
+(ddp(X[4 * rank: 4 * rank + 4]) ** 2).sum().backward()  # autograd accumulates in place into the flat-buffer views
+assert bucket._work is None
+bucket._layer_done()                                     # l2's sink ...
+assert bucket._work is None
+bucket._layer_done()                                     # ... l1's sink: the LAST attached layer issues the all-reduce
+assert bucket._work is not None
+scale = bucket.wait()
+assert abs(scale - 0.5) < 1e-12 and bucket._arrived == 0
+(ref(X) ** 2).sum().backward()
+ref_f = [ref.l1.downscale_weights[0], ref.l1.upscale_weights[0], ref.l2.downscale_weights[0], ref.l2.upscale_weights[0]]
+for p, q in zip(factors, ref_f):
+    assert p.grad.data_ptr() == bucket.grad_ptr(p)
+    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (p.grad - q.grad).abs().max()   # SUM over ranks == full batch
+assert torch.allclose(net.head.weight.grad, ref.head.weight.grad / world, rtol=1e-5, atol=1e-6)    # DDP averaged the rest
+# fused optimizer refuses to step on stale views; accumulate()-style re-init differs per rank until the broadcast
+opt = FactorAdamW.__new__(FactorAdamW); opt.bucket = bucket
+torch.manual_seed(100 + rank)
+for m in (net.l1, net.l2):
+    m.next_draws = [torch.randn(m.in_features, m.rank) * 0.02]
+    m.accumulate()
+try:
+    FactorAdamW.step(opt)
+    raise SystemExit("stale factor views were not detected")
+except RuntimeError as e:
+    assert "rebind" in str(e)
+bucket.rebind()
+assert all(p.data_ptr() == bucket.flat_param.data_ptr() + o * 4 for p, o in zip(bucket.params, bucket.offsets))
+mine = net.l1.downscale_weights[0].data.clone()
+bucket.broadcast_factors(src=0)
+got = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(got, net.l1.downscale_weights[0].data.clone())
+assert torch.equal(got[0], got[1])                       # re-initialised A identical on both ranks
+assert (rank == 0) == torch.equal(mine, got[0])
+assert float(net.l1.upscale_weights[0].abs().max()) == 0.0 and tuple(net.l1.acc_downweight.shape) == (12, 4)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_bucket_protocol_with_ddp_gloo_world2(tmp_path):
+    """SURVEY 8e end to end on 2 CPU ranks: factors in the flat bucket (ONE sum all-reduce, issued when the last
+    attached layer reports in), everything else through DistributedDataParallel with the factors on its ignore list;
+    summed factor gradients == single-process gradients on the concatenated batch; after an accumulate() with
+    rank-dependent re-initialisation draws, rebind() + broadcast_factors() make A identical everywhere."""
+    store = str(tmp_path / "store")
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_DP_PROTOCOL_WORKER)
+    procs = [subprocess.Popen([sys.executable, script, str(r), store, ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_attach_refuses_a_ddp_wrapped_model_and_optimizer_state_round_trips():
+    from sow_amd import FactorBucket, SoWLinear, factor_parameters
+    from sow_amd.optimizer import FactorAdamW
+    net = nn.Sequential(SoWLinear(12, 10, bias=False, rank=4, init_method="normal"))
+    bucket = FactorBucket(factor_parameters(net))
+
+    class FakeDDP(torch.nn.parallel.DistributedDataParallel):
+        def __init__(self):       # no process group needed for the isinstance check
+            nn.Module.__init__(self)
+
+    with pytest.raises(RuntimeError, match="exclude_from_ddp"):
+        bucket.attach(FakeDDP())
+    opt = FactorAdamW(bucket, lr=3e-3, betas=(0.9, 0.95), eps=1e-6, weight_decay=0.1, state_dtype=torch.float32)
+    opt.exp_avg.normal_()
+    opt.exp_avg_sq.uniform_()
+    opt.step_count = 7
+    opt.param_groups[0]["lr"] = 1e-3            # what an LR scheduler does
+    sd = opt.state_dict()
+    assert sd["lr"] == 3e-3                     # not yet synced: schedulers' writes take effect on the next read of param_groups
+    assert opt.param_groups[0]["lr"] == 1e-3 and opt.lr == 1e-3
+    other = FactorAdamW(bucket, state_dtype=torch.float32)
+    other.load_state_dict(opt.state_dict())
+    assert other.step_count == 7 and other.lr == 1e-3 and other.betas == (0.9, 0.95) and other.weight_decay == 0.1
+    assert torch.equal(other.exp_avg, opt.exp_avg) and torch.equal(other.exp_avg_sq, opt.exp_avg_sq)
+    with pytest.raises(ValueError):
+        FactorAdamW(FactorBucket([nn.Parameter(torch.zeros(5))])).load_state_dict(sd)
