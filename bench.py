@@ -103,40 +103,51 @@ class Stack:
             params += [self.A[-1], self.B[-1]]
             self.W.append((torch.randn(d_in, d_out, generator=g, device=device) * 0.02).to(dtype) if acc == "dense" else None)
         self.bucket = FactorBucket(params)  # params / grads are views into two flat buffers
-        # outputs rotate through a few buffers per width (a real model frees activations it no longer needs)
-        widths = {s[0] for s in shapes} | {s[1] for s in shapes}
-        pool = {d: [torch.empty(T, d, dtype=dtype, device=device) for _ in range(4)] for d in widths}
+        # every layer writes its OWN y and dX buffer (activations and their gradients are distinct live tensors in a
+        # model; a buffer re-used by successive layers would have its writes absorbed by the 256 MiB Infinity Cache)
         self.calls = []
         for li, (d_in, d_out) in enumerate(shapes):
             ws = torch.empty(ops.workspace_bytes(T, d_in, d_out, r, 0, kind, dtype) + 256, dtype=torch.uint8, device=device)
             self.calls.append(ops.LayerCall(self.x[li], self.A[li].data, self.B[li].data, acc_down=self.W[li], scale=1.0,
-                                            y=pool[d_out][li % 4], dy2=self.dy[li], dx=pool[d_in][(li + 2) % 4],
+                                            y=torch.empty(T, d_out, dtype=dtype, device=device), dy2=self.dy[li],
+                                            dx=torch.empty(T, d_in, dtype=dtype, device=device),
                                             out=(self.A[li].grad, self.B[li].grad, None), grad_beta=0.0, workspace=ws))
         nb = len(BLOCK_NAMES)
         layout = BLOCK_GROUPS if group == "block" else [[i] for i in range(nb)]
         self.group_layers = [[blk * nb + i for i in idx] for blk in range(len(shapes) // nb) for idx in layout]
         self.groups = [ops.LayerGroup([self.calls[li] for li in ids]) for ids in self.group_layers]
+        # weight-gradient partial sums: nothing consumes them before the optimizer, so ALL layers of a decoder block go
+        # into one launch after the block's data-gradient kernels (dY / dh of 7 layers stay alive that long: ~0.4 GB)
+        self.tn_layers = ([[blk * nb + i for i in range(nb)] for blk in range(len(shapes) // nb)] if group == "block"
+                          else self.group_layers)
+        self.tn_groups = [ops.LayerGroup([self.calls[li] for li in ids]) for ids in self.tn_layers]
 
     def forward_all(self, only=None):
         for gi, grp in enumerate(self.groups):
             if only is None or gi in only:
                 grp.forward()
 
-    def backward_all(self, only=None, phases=None):
-        """Backward in reverse order; per group the data-gradient kernels (dX: what the previous layer's backward
-        waits for in a real model) run first, then the weight-gradient partial sums; ONE batched reduction at the end."""
+    def backward_all(self, only=None, phases=None, tn_only=None):
+        """Backward in reverse order.  Per decoder block: the data-gradient kernels of its groups (dX: what the previous
+        layer's backward waits for in a real model), then ONE launch of the weight-gradient partial sums of the whole
+        block; ONE batched reduction at the very end.  `only` / `phases` / `tn_only` restrict the work for the per-launch
+        timings."""
         from sow_amd import _lib
-        ph = phases if phases is not None else (_lib.BWD_DATA | (_lib.BWD_WEIGHTS_PARTIAL if self.deferred is not None else _lib.BWD_WEIGHTS))
+        full = phases is None and only is None and tn_only is None
+        first_of_block = {min(gi for gi, ids in enumerate(self.group_layers) if ids[0] in set(tl)): ti
+                          for ti, tl in enumerate(self.tn_layers)}
         for gi in reversed(range(len(self.groups))):
-            if only is not None and gi not in only:
-                continue
-            self.groups[gi].backward(ph)
-            if self.deferred is not None and phases is None:
-                for li in reversed(self.group_layers[gi]):
-                    c = self.calls[li]
-                    self.deferred.add(self.x[li], self.B[li].data, (self.A[li].grad, self.B[li].grad, None), 0.0, c.workspace,
-                                      self.W[li], None)
-        if self.deferred is not None and phases is None:
+            if (full or (phases == _lib.BWD_DATA and (only is None or gi in only))):
+                self.groups[gi].backward(_lib.BWD_DATA)
+            ti = first_of_block.get(gi)        # the block's first group is its last in backward order: then its weights
+            if ti is not None and (full or (phases == _lib.BWD_WEIGHTS_PARTIAL and (tn_only is None or ti in tn_only))):
+                self.tn_groups[ti].backward(_lib.BWD_WEIGHTS_PARTIAL if (self.deferred is not None or not full) else _lib.BWD_WEIGHTS)
+                if self.deferred is not None and full:
+                    for li in reversed(self.tn_layers[ti]):
+                        c = self.calls[li]
+                        self.deferred.add(self.x[li], self.B[li].data, (self.A[li].grad, self.B[li].grad, None), 0.0, c.workspace,
+                                          self.W[li], None)
+        if self.deferred is not None and full:
             self.deferred.run()
 
     def step(self):
@@ -334,15 +345,23 @@ def per_launch_table(stack, stream, T, r, es):
     for label, gi, shp in launch_kinds(stack):
         only = {blk * ngroups + gi for blk in range(nblk)}
         chain_bytes = sum(T * (di + do + r) * es for di, do in shp)
-        tn_bytes = sum(T * (di + do + 2 * r) * es for di, do in shp)
-        for tag, fn, nbytes in (
-                ("fwd chain", lambda: stack.forward_all(only), chain_bytes),
-                ("bwd chain (dX)", lambda: stack.backward_all(only, _lib.BWD_DATA), chain_bytes),
-                ("bwd weight partials", lambda: stack.backward_all(only, _lib.BWD_WEIGHTS_PARTIAL), tn_bytes)):
+        for tag, fn in (("fwd chain", lambda: stack.forward_all(only)),
+                        ("bwd chain (dX)", lambda: stack.backward_all(only, _lib.BWD_DATA))):
             us = time_graph(fn, stream) / nblk * 1e3
-            gbs = nbytes / us / 1e3
+            gbs = chain_bytes / us / 1e3
             table[f"{tag}: {label}"] = {"us": round(us, 2), "GB/s": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 3),
-                                        "algorithmic_MB": round(nbytes / 1e6, 2)}
+                                        "algorithmic_MB": round(chain_bytes / 1e6, 2)}
+    ntn = len(stack.tn_groups) // nblk
+    for k in range(ntn):
+        ids = stack.tn_layers[k]
+        shp = [stack.shapes[i] for i in ids]
+        tn_bytes = sum(T * (di + do + 2 * r) * es for di, do in shp)
+        only = {blk * ntn + k for blk in range(nblk)}
+        us = time_graph(lambda: stack.backward_all(None, _lib.BWD_WEIGHTS_PARTIAL, only), stream) / nblk * 1e3
+        gbs = tn_bytes / us / 1e3
+        names = "+".join(BLOCK_NAMES[i % len(BLOCK_NAMES)] for i in ids)
+        table[f"bwd weight partials: {names} ({len(ids)} layers)"] = {
+            "us": round(us, 2), "GB/s": round(gbs), "frac": round(gbs / HBM_PEAK_GBS, 3), "algorithmic_MB": round(tn_bytes / 1e6, 2)}
     return table
 
 
@@ -501,7 +520,8 @@ def main():
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
                        "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": head["graph"],
                        "weight_grad_reduce": args.reduce,
-                       "launch_grouping": "per decoder block: {q,k,v} {o} {gate,up} {down}" if args.group == "block" else "one call per layer"},
+                       "launch_grouping": ("per decoder block: {q,k,v} {o} {gate,up} {down} for the chain kernels, all 7 layers for the "
+                                           "weight-gradient partial sums; resident (persistent) workgroups") if args.group == "block" else "one call per layer"},
             "gflops": head["flops"] * world / (ms * 1e-3) / 1e9,
             "algorithmic_gbytes_per_step": head["nbytes"] / 1e9,
             "step_hbm_gbs": head["nbytes"] / (ms * 1e-3) / 1e9,

@@ -53,6 +53,7 @@ constexpr int C2_RING0 = C2_NSLOT * C2_FSLOT;
 constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 24 KiB per token group
 constexpr int C2_LDS = C2_RING0 + C2_NTG * C2_RING;   // 80 KiB: two workgroups per CU
 constexpr int C2_THREADS = 64 * (C2_NCW + C2_NLW);
+constexpr int C2_RESIDENT = 512;      // resident workgroups of a persistent grid (2 per CU x 256 CUs)
 
 
 template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
@@ -69,17 +70,9 @@ template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
 // 5.1 TB/s), so three 512-workgroup layers in one 1536-workgroup grid pay it once; later rounds start while earlier
 // workgroups drain.  Every workgroup runs exactly the single-layer code on its own layer's parameter block, so the
 // results are bit-identical to separate launches.
-template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kernel(const ChainGroup grp) {
+template <bool BWD>
+__device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid, char* smem, const int t, const int lane, const int w) {
   constexpr bool TR = !BWD;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  int layer = 0;
-#pragma unroll
-  for (int i = 1; i < C2_MAXG; ++i)
-    if (i < grp.n && (int)blockIdx.x >= grp.start[i]) layer = i;
-  const ChainParams& p = grp.p[layer];
-  const int bid = (int)blockIdx.x - grp.start[layer];
   // short-T split (kernels.hpp): workgroup = (token block, split); a split owns a range of phase-1 stages OR of
   // phase-2 slices.  Without a split every workgroup owns all of both.
   const int tb = p.ntb > 0 ? bid % p.ntb : bid;
@@ -175,6 +168,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
       raw_barrier();
       raw_barrier();
     }
+    raw_barrier();     // end of block: the compute waves have read the last parked slice out of the rings
     return;
   }
 
@@ -484,6 +478,34 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 3) void chain2_kern
     raw_barrier();   // the partner has parked the last slice
     flush(nsl - 1);
   }
+  raw_barrier();     // end of block: every LDS read of this block has returned -- the next block's DMA may overwrite the rings
+}
+
+// Grouped, persistent launch: the grid is min(total, C2_RESIDENT) workgroups (two per CU); workgroup g runs token blocks
+// g, g + grid, g + 2 grid, ... of the concatenated block list of up to C2_MAXG independent layers (same direction; shapes
+// may differ) -- e.g. the q / k / v projections of an attention block, or gate / up of an MLP.  Why: a 64-token
+// workgroup that is launched, streams 64 KB in, 64 KB out and exits costs ~20 us per round at 512 -> 512 against
+// ~14 us of streaming (tools/chain_sweep.py: t = 8.6 us + bytes / 5.1 TB/s) -- workgroup launch, first-load latency and
+// the drain of its stores before the slot is free again are per-workgroup costs that a multi-round grid pays every
+// round.  A resident workgroup issues the next block's first loads right after its last stores: the store drain and
+// the load latency overlap, and nothing is relaunched.  Every block runs exactly the single-layer code on its own
+// layer's parameter block, so the results are bit-identical to separate launches.
+template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(const ChainGroup grp) {   // 4 waves per SIMD: caps the allocation at 128 VGPRs, above which a CU cannot place two of these workgroups
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int total = grp.start[C2_MAXG];
+  for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < C2_MAXG; ++i)
+      if (i < grp.n && blk >= grp.start[i]) layer = i;
+    // opaque per iteration: keeps the per-lane address arithmetic of a block inside its iteration -- hoisted out of the
+    // loop by LICM it stays live across the whole block (168 VGPRs instead of ~100; above 128 a CU holds one workgroup)
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    chain2_block<BWD>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w);
+  }
 }
 
 // =================================================================================================
@@ -568,12 +590,14 @@ int launch_chain2_group(const ChainParams* ps, int n, bool bwd, hipStream_t stre
   for (int i = n; i <= C2_MAXG; ++i) g.start[i] = (int)total;
   if (total <= 0) return SOW_OK;
   if (total > 0x7fffffff) return SOW_ERR_SHAPE;
+  // persistent when the block list exceeds one resident round (two 80-KiB workgroups per CU x 256 CUs)
+  const int64_t grid = (sw_on(SW_NO_PERSIST) || total < C2_RESIDENT) ? total : C2_RESIDENT;
   if (bwd) {
     SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<true>);
-    hipLaunchKernelGGL(chain2_kernel<true>, dim3((unsigned)total), dim3(C2_THREADS), C2_LDS, stream, g);
+    hipLaunchKernelGGL(chain2_kernel<true>, dim3((unsigned)grid), dim3(C2_THREADS), C2_LDS, stream, g);
   } else {
     SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<false>);
-    hipLaunchKernelGGL(chain2_kernel<false>, dim3((unsigned)total), dim3(C2_THREADS), C2_LDS, stream, g);
+    hipLaunchKernelGGL(chain2_kernel<false>, dim3((unsigned)grid), dim3(C2_THREADS), C2_LDS, stream, g);
   }
   SOW_CHECK_LAUNCH();
   return SOW_OK;

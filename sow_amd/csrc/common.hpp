@@ -130,6 +130,7 @@ enum Switch : int {
   SW_GEMM3S,              // 1 / 0: force / forbid gemm3s
   SW_GEMM3,               // 1 / 0: force / forbid gemm3
   SW_NO_GROUPED,          // grouped (multi-layer) entry points launch layer by layer
+  SW_NO_PERSIST,          // grouped grids launch one workgroup per token block instead of resident workgroups that loop
   SW_COUNT
 };
 int sw(int which);

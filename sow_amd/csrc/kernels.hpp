@@ -84,7 +84,7 @@ struct ReduceParams {
 int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len);
 size_t tn_partial_bytes(int ns, int D);
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
-constexpr int TN_MAXG = 4;   // layers per grouped launch of the wide bf16 kernel
+constexpr int TN_MAXG = 8;   // layers per grouped launch of the wide bf16 kernel (a decoder block has 7)
 struct TnGroup {
   TnParams p[TN_MAXG];
   int start[TN_MAXG + 1];

@@ -391,18 +391,8 @@ __device__ __forceinline__ void tnw_wait_stages(int newer) {   // 6 DMA instruct
   }
 }
 
-// Grouped launch (TnGroup): the grids of up to TN_MAXG layers back to back; every workgroup runs the single-layer code
-// on its layer's parameters (bit-identical partials), the ~8 us of launch ramp and drain are paid once per group.
-__global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(const TnGroup grp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  int layer = 0;
-#pragma unroll
-  for (int i = 1; i < TN_MAXG; ++i)
-    if (i < grp.n && (int)blockIdx.x >= grp.start[i]) layer = i;
-  const TnParams& p = grp.p[layer];
-  int b = (int)blockIdx.x - grp.start[layer], jid = 0;
+__device__ __forceinline__ void tnw_block(const TnParams& p, int b, char* smem, const int t, const int lane, const int w) {
+  int jid = 0;
   const int ncg2_0 = (p.job[0].ncg + 1) / 2;
   if (p.njobs > 1 && b >= ncg2_0 * p.ns) {
     b -= ncg2_0 * p.ns;
@@ -537,6 +527,27 @@ __global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(
       *(f32x4*)(P + v * 4) = s0;
     }
     __syncthreads();
+  }
+}
+
+// Grouped, persistent launch (TnGroup): the block lists of up to TN_MAXG layers back to back, run by min(total, 256)
+// resident workgroups (one per CU: 144 KiB of LDS) that loop over them -- workgroup launch, ring prologue and the drain of
+// the partial stores are paid once per resident workgroup instead of once per block; weight gradients have no consumer
+// before the optimizer, so a whole decoder block's layers (7 for llama) go into ONE launch.  Every block runs the
+// single-layer code on its layer's parameters: bit-identical partials.
+__global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(const TnGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int total = grp.start[TN_MAXG];
+  for (int blk = (int)blockIdx.x; blk < total; blk += (int)gridDim.x) {
+    int layer = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAXG; ++i)
+      if (i < grp.n && blk >= grp.start[i]) layer = i;
+    int tt = t;
+    asm volatile("" : "+v"(tt));   // keeps per-lane address arithmetic inside the iteration (see chain2.hip)
+    tnw_block(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w);
   }
 }
 
@@ -842,7 +853,8 @@ int launch_tn_group(const TnParams* ps, int n, hipStream_t stream) {
   if (total > 0x7fffffff) return SOW_ERR_SHAPE;
   constexpr int LDS = TNW_WAVES * TNW_DEPTH * TNW_STAGE_BYTES;  // 144 KiB (rings; reused by the cross-wave sum)
   SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
-  hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3((unsigned)total), dim3(64 * TNW_WAVES), LDS, stream, g);
+  const int64_t grid = (sw_on(SW_NO_PERSIST) || total < 256) ? total : 256;   // one resident workgroup per CU
+  hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3((unsigned)grid), dim3(64 * TNW_WAVES), LDS, stream, g);
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }
