@@ -2,12 +2,19 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := sow_amd/csrc
+ifdef STAMPS
+OBJDIR  := build/obj_stamps
+LIB     := sow_amd/lib/libsow_amd_stamps.so
+EXTRA   := -DSOW_STAMPS
+else
 OBJDIR  := build/obj
 LIB     := sow_amd/lib/libsow_amd.so
+EXTRA   :=
+endif
 SRCS    := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS    := $(wildcard $(CSRC)/*.hpp) include/sow_amd.h
-CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-variable \
+CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) $(EXTRA) -Wall -Wno-unused-function -Wno-unused-variable \
             -Wno-unused-but-set-variable
 
 all: $(LIB)

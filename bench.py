@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
                     help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
                          "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
+    ap.add_argument("--tn-group", choices=["block", "group"], default="block",
+                    help="weight-gradient partial sums: one launch per decoder block (7 layers, after the block's data-gradient "
+                         "kernels) or one per launch group, right after that group's data-gradient kernel (dY still in the "
+                         "Infinity Cache)")
     ap.add_argument("--group", choices=["block", "none"], default="block",
                     help="block: {q,k,v} and {gate,up} of a decoder block share launches (grouped C-ABI calls); none: one call per layer")
     return ap.parse_args()
@@ -83,7 +87,7 @@ def parse():
 class Stack:
     """The 56-layer SoWLinear stack with resident synthetic inputs and static output buffers."""
 
-    def __init__(self, shapes, T, r, dtype, device, acc, reduce="batch", group="block"):
+    def __init__(self, shapes, T, r, dtype, device, acc, reduce="batch", group="block", tn_group="block"):
         from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
@@ -118,8 +122,8 @@ class Stack:
         self.groups = [ops.LayerGroup([self.calls[li] for li in ids]) for ids in self.group_layers]
         # weight-gradient partial sums: nothing consumes them before the optimizer, so ALL layers of a decoder block go
         # into one launch after the block's data-gradient kernels (dY / dh of 7 layers stay alive that long: ~0.4 GB)
-        self.tn_layers = ([[blk * nb + i for i in range(nb)] for blk in range(len(shapes) // nb)] if group == "block"
-                          else self.group_layers)
+        self.tn_layers = ([[blk * nb + i for i in range(nb)] for blk in range(len(shapes) // nb)]
+                          if (group == "block" and tn_group == "block") else self.group_layers)
         self.tn_groups = [ops.LayerGroup([self.calls[li] for li in ids]) for ids in self.tn_layers]
 
     def forward_all(self, only=None):
@@ -371,7 +375,7 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
     es = 2 if dtype_name == "bf16" else 4
     shapes = layer_shapes()
     T = args.tokens
-    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group)
+    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group, args.tn_group)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
 

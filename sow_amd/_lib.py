@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsow_amd.so")
+# SOW_AMD_LIB: an alternative build of the same library (the `make STAMPS=1` timeline build used by tools/chain_stamps.py)
+LIB_PATH = os.environ.get("SOW_AMD_LIB") or os.path.join(_HERE, "lib", "libsow_amd.so")
 
 F32, BF16 = 0, 1
 ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 // ---- kernel-selection switches (common.hpp: enum Switch) ----------------------------------------------
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
-                                                   "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST"};
+                                                   "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -128,6 +128,14 @@ int sow_set_switch(const char* name, int value) {
     }
   return SOW_ERR_UNSUPPORTED;
 }
+
+#ifdef SOW_STAMPS
+// debug builds only (not declared in include/sow_amd.h): device buffer for the in-kernel timeline of chain2_kernel
+int sow_debug_set_stamps(void* buf) {
+  g_chain2_stamps = buf;
+  return SOW_OK;
+}
+#endif
 
 int sow_get_switch(const char* name) {
   if (!name) return SOW_ERR_NULL;

@@ -39,6 +39,19 @@
 
 namespace sow {
 
+// In-kernel timeline (debug builds only: `make STAMPS=1` -> libsow_amd_stamps.so, tools/chain_stamps.py): wave 0 of every
+// workgroup writes s_memrealtime (100 MHz) at the phase boundaries of every block it runs into grp.stamps[block][8].
+#ifdef SOW_STAMPS
+#define C2_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (stamps && w == 0 && lane == 0) stamps[i] = __builtin_amdgcn_s_memrealtime();                \
+  } while (0)
+#else
+#define C2_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 constexpr int C2_NTG = 2;             // token groups (32 tokens) per workgroup
 constexpr int C2_NCW = 2 * C2_NTG;    // compute waves: (token group, half)
 constexpr int C2_NLW = 2;             // loader waves
@@ -71,8 +84,10 @@ template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
 // workgroups drain.  Every workgroup runs exactly the single-layer code on its own layer's parameter block, so the
 // results are bit-identical to separate launches.
 template <bool BWD>
-__device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid, char* smem, const int t, const int lane, const int w) {
+__device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid, char* smem, const int t, const int lane, const int w,
+                                             uint64_t* stamps) {
   constexpr bool TR = !BWD;
+  C2_STAMP(0);
   // short-T split (kernels.hpp): workgroup = (token block, split); a split owns a range of phase-1 stages OR of
   // phase-2 slices.  Without a split every workgroup owns all of both.
   const int tb = p.ntb > 0 ? bid % p.ntb : bid;
@@ -220,7 +235,8 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     for (int ii = 0; ii < 2; ++ii) {
       const char* qq = xsrc[ii] + (st0 + st) * xstride[ii];
       if (x_ragged && (st0 + st) * 64 + xlc[ii] * 8 >= D1) qq = zp;
-      dma16((const void*)qq, dst + (2 * hh + ii) * 1024);
+      if (p.nt_load) dma16_nt((const void*)qq, dst + (2 * hh + ii) * 1024);
+      else dma16((const void*)qq, dst + (2 * hh + ii) * 1024);
     }
   };
 
@@ -265,6 +281,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     const int newer = (nst - 1 - st) < (C2_DEPTH - 2) ? (nst - 1 - st) : (C2_DEPTH - 2);
     wait_groups<2>(newer);   // this wave's half of X stage `st` has landed
     raw_barrier();           // ... and so have the partner's half and factor chunk `st`
+    if (st == 0) C2_STAMP(1);
     if (st + C2_DEPTH - 1 < nst) issue_x(st + C2_DEPTH - 1);   // into the slot of stage st-1
     const uint32_t xs = ring_a + (uint32_t)((st % C2_DEPTH) * C2_STAGE) + xoff;
     const uint32_t fs = slot_a + (uint32_t)((st % C2_NSLOT) * C2_FSLOT);
@@ -304,6 +321,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  C2_STAMP(2);
   // ================================================================== hand-off: sum the two K halves
   // barrier H0: every X read of the workgroup is done, so the rings can hold the exchange buffers
   // (fp32 [wave][tile][reg][lane], 8 KiB per wave); barrier H1: partials visible to the partner.
@@ -386,6 +404,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   }
 
   }
+  C2_STAMP(3);
   // ================================================================== phase 2: Y^T = F2^T . H^T (column tile hh)
   // Epilogue: Y^T has one token per lane, so a direct store would write 8-byte pieces of 32 different
   // rows (measured: 2x the time of full-row stores).  Each slice is transposed through a per-token-group
@@ -431,8 +450,13 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)bb[e];
         }
-        *(u32x4*)dst = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                pack_bf16x2(v[6], v[7])};
+        // streaming (non-temporal) store: Y is not read again by this kernel.  Without the hint up to 32 MB of dirty lines sit
+        // in the eight L2s when the last workgroup ends and are written back before the next kernel may start (the XCDs'
+        // L2s are not coherent with each other): 512 -> 512 forward 23.0 -> 19.7 us per launch, step 4.48 -> 4.23 ms.
+        // ("sc0 sc1" write-through: 22.3 us; "sc0 sc1 nt": 19.2 us -- no better than nt alone.)
+        const u32x4 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(ov) : "memory");
+        else *(u32x4*)dst = ov;
       }
     }
   };
@@ -474,11 +498,14 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
       *(f32x4*)(ring + (sl & 1) * 8192 + li * 256 + ((chunk ^ (li & 15)) * 16)) = v;
     }
   }
+  C2_STAMP(4);
   if (nsl > 0) {
     raw_barrier();   // the partner has parked the last slice
     flush(nsl - 1);
   }
+  C2_STAMP(5);
   raw_barrier();     // end of block: every LDS read of this block has returned -- the next block's DMA may overwrite the rings
+  C2_STAMP(6);
 }
 
 // Grouped, persistent launch: the grid is min(total, C2_RESIDENT) workgroups (two per CU); workgroup g runs token blocks
@@ -504,7 +531,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kern
     // loop by LICM it stays live across the whole block (168 VGPRs instead of ~100; above 128 a CU holds one workgroup)
     int tt = t;
     asm volatile("" : "+v"(tt));
-    chain2_block<BWD>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w);
+    chain2_block<BWD>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w, grp.stamps ? grp.stamps + (int64_t)blk * 8 : nullptr);
   }
 }
 
@@ -560,6 +587,8 @@ int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, i
   return SOW_OK;
 }
 
+void* g_chain2_stamps = nullptr;   // debug builds: device buffer [blocks][8] of u64 (sow_debug_set_stamps)
+
 static int chain2_grid(const ChainParams& p) {
   // B is DMA'd in aligned 16-byte pieces along its rows; A must be contiguous [rows, r] and 4-byte aligned
   if (p.ntb > 0) {
@@ -584,10 +613,13 @@ int launch_chain2_group(const ChainParams* ps, int n, bool bwd, hipStream_t stre
     if ((reinterpret_cast<uintptr_t>(Bp) & 15) || ldB % 8 || (reinterpret_cast<uintptr_t>(Ap) & 3) || ldA != p.rb)
       return SOW_ERR_ALIGN;
     g.p[i] = p;
+    g.p[i].nt_store = sw_on(SW_NO_NT_STORE) ? 0 : 1;
+    g.p[i].nt_load = sw_on(SW_NT_LOAD) ? 1 : 0;
     g.start[i] = (int)total;
     total += chain2_grid(p);
   }
   for (int i = n; i <= C2_MAXG; ++i) g.start[i] = (int)total;
+  g.stamps = (uint64_t*)g_chain2_stamps;
   if (total <= 0) return SOW_OK;
   if (total > 0x7fffffff) return SOW_ERR_SHAPE;
   // persistent when the block list exceeds one resident round (two 80-KiB workgroups per CU x 256 CUs)

@@ -131,6 +131,8 @@ enum Switch : int {
   SW_GEMM3,               // 1 / 0: force / forbid gemm3
   SW_NO_GROUPED,          // grouped (multi-layer) entry points launch layer by layer
   SW_NO_PERSIST,          // grouped grids launch one workgroup per token block instead of resident workgroups that loop
+  SW_NO_NT_STORE,         // plain (cached) Y stores in the chain kernel instead of non-temporal ones
+  SW_NT_LOAD,             // experiment: non-temporal X loads in the chain kernel
   SW_COUNT
 };
 int sw(int which);

@@ -27,6 +27,8 @@ struct ChainParams {
   int ntb, st_per, sl_per;
   float* Hpartial;
   const void* Hload;
+  int nt_store;   // chain2: write Y with the non-temporal hint
+  int nt_load;    // chain2 (experiment): stream X with the non-temporal hint
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
@@ -35,7 +37,9 @@ struct ChainGroup {
   ChainParams p[C2_MAXG];
   int start[C2_MAXG + 1];    // first workgroup of layer i; start[n..] = grid size
   int n;
+  uint64_t* stamps;          // debug builds (SOW_STAMPS): [blocks][8] timeline, else nullptr
 };
+extern void* g_chain2_stamps;
 bool chain2_supported(const ChainParams& p, int dtype);
 int launch_chain2(const ChainParams& p, bool bwd, hipStream_t stream);
 // one grid for n <= C2_MAXG independent layers of the same direction (each one chain2_supported)

@@ -52,6 +52,11 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux bit 1 = nt on gfx94x/gfx950): streamed-once operands
+__device__ __forceinline__ void dma16_nt(const void* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+}
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0], lo[1], hi[0], hi[1]}; }
 }  // namespace sow
