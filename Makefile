@@ -6,6 +6,11 @@ ifdef STAMPS
 OBJDIR  := build/obj_stamps
 LIB     := sow_amd/lib/libsow_amd_stamps.so
 EXTRA   := -DSOW_STAMPS
+else ifdef VARIANT
+# A/B builds: make VARIANT=name DEFS="-DSOMETHING" -> sow_amd/lib/libsow_amd_name.so (select with SOW_AMD_LIB=...)
+OBJDIR  := build/obj_$(VARIANT)
+LIB     := sow_amd/lib/libsow_amd_$(VARIANT).so
+EXTRA   := $(DEFS)
 else
 OBJDIR  := build/obj
 LIB     := sow_amd/lib/libsow_amd.so

@@ -172,6 +172,31 @@ size_t sow_qr_workspace_bytes(int m, int n, int k, int in_dtype, int need_r);
 int sow_qr_thin(const void* W, int64_t ldw, int m, int n, int in_dtype, int k, void* Q_out, int64_t ldq, void* R_out,
                 int64_t ldr, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The periodic step of MANY layers -- replaces the loop of tn_gradient/prepare.py:219-222 over
+ * SoWLinear.accumulate (sow.py:128-178) for layers on the dense-accumulator branch (the one every script takes:
+ * prepare.py:120 forces virtual_rank = min(in, out)).  Per item, in stream order:
+ *     acc   = acc_beta * acc + scale * A . B          (sow.py:131-140; acc_beta = 0 materialises a first accumulator)
+ *     A_new = Q[:, :r_new] of the Householder QR of `draw` [d_in, draw_cols]   (sow.py:161-172; skipped when draw = NULL)
+ *     `zero` buffer <- 0                                (B <- 0, sow.py:159)
+ * One launch per phase for all items (the per-layer QR panel is latency-bound on one CU; n of them run side by side).
+ * A_new may alias A: it is written after the update has consumed A.  Workspace per item:
+ * sow_qr_workspace_bytes(d_in, draw_cols, r_new, dtype, 0).  r <= 64. */
+typedef struct sow_accumulate_args {
+  void* acc;
+  const void* A;
+  const void* B;
+  const void* draw;
+  int64_t ld_draw;
+  void* A_new;
+  void* zero;
+  int64_t zero_bytes;
+  int32_t d_in, d_out, r, r_new, draw_cols;
+  float scale, acc_beta;
+  void* workspace;
+  size_t workspace_bytes;
+} sow_accumulate_args;
+int sow_accumulate_batch(const sow_accumulate_args* items, int n, int dtype, void* stream);
+
 /* Multi-tensor zero fill -- replaces the per-parameter torch.zeros_like of reset_optimizer
  * (scripts/utils/training_utils.py:257-277) and B <- 0 of sow.py:159.  ptrs/bytes are HOST arrays. */
 int sow_zero_state(void* const* ptrs, const int64_t* bytes, int n, void* stream);

@@ -30,6 +30,14 @@ class LayerArgs(ctypes.Structure):
                 ("scale", c_float), ("grad_beta", c_float), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
+class AccumulateArgs(ctypes.Structure):
+    """sow_accumulate_args of include/sow_amd.h."""
+    _fields_ = [("acc", c_void_p), ("A", c_void_p), ("B", c_void_p), ("draw", c_void_p), ("ld_draw", c_int64),
+                ("A_new", c_void_p), ("zero", c_void_p), ("zero_bytes", c_int64), ("d_in", ctypes.c_int32),
+                ("d_out", ctypes.c_int32), ("r", ctypes.c_int32), ("r_new", ctypes.c_int32), ("draw_cols", ctypes.c_int32),
+                ("scale", c_float), ("acc_beta", c_float), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 # name -> (restype, argtypes); mirrors include/sow_amd.h one to one
 SIGNATURES = {
     "sow_version": (c_int, []),
@@ -47,6 +55,7 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_int, c_void_p]),
     "sow_forward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_void_p]),
     "sow_backward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p]),
+    "sow_accumulate_batch": (c_int, [POINTER(AccumulateArgs), c_int, c_int, c_void_p]),
     "sow_reduce_desc_bytes": (c_size_t, []),
     "sow_backward_reduce_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                          c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -4,6 +4,7 @@
 // table of kernel-selection switches below (atomics, read from the environment once).
 #include "kernels.hpp"
 #include <cstring>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -539,7 +540,8 @@ int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stre
   if (n == 0) return SOW_OK;
   if (!layers) return SOW_ERR_NULL;
   ChainParams batch[C2_MAXG];
-  int nb = 0, rc;
+  Gemm2hArgs gbatch[4];
+  int nb = 0, ng = 0, rc;
   for (int i = 0; i < n; ++i) {
     const sow_layer_args& L = layers[i];
     if ((rc = check_layer(L, false))) return rc;
@@ -552,10 +554,23 @@ int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stre
       }
       continue;
     }
+    // dense accumulator, one launch per layer (gemm2h): the layers of a group share the grid
+    if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 && L.h_save && !sw_on(SW_NO_GROUPED) &&
+        gemm2h_supported(L.x, L.d_in, L.acc_down, L.d_out, false, L.A, L.r_live, L.B, L.d_out, L.y, L.d_out, L.bias, L.h_save, L.T,
+                         L.d_out, L.d_in, L.r_live, dtype)) {
+      gbatch[ng] = Gemm2hArgs{L.x, L.acc_down, L.A, L.B, L.y, L.bias, L.h_save, L.T, L.d_in, L.d_out, L.r_live, L.d_out, L.d_out,
+                              L.d_out, L.d_in, L.r_live, L.scale};
+      if (++ng == 4) {
+        if ((rc = launch_gemm2h_group(gbatch, ng, false, stream))) return rc;
+        ng = 0;
+      }
+      continue;
+    }
     rc = sow_forward(L.x, L.A, L.B, L.acc_down, L.acc_up, L.bias, L.y, L.h_save, L.T, L.d_in, L.d_out, L.r_live, L.r_acc,
                      L.acc_kind, L.scale, dtype, L.workspace, L.workspace_bytes, stream_);
     if (rc) return rc;
   }
+  if (ng && (rc = launch_gemm2h_group(gbatch, ng, false, stream))) return rc;
   return nb ? launch_chain2_group(batch, nb, false, stream) : SOW_OK;
 }
 
@@ -582,7 +597,8 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
   };
   if (do_data) {
     ChainParams batch[C2_MAXG];
-    int nb = 0;
+    Gemm2hArgs gbatch[4];
+    int nb = 0, ng = 0;
     for (int i = 0; i < n; ++i) {
       const sow_layer_args& L = layers[i];
       if (L.T == 0) {
@@ -591,14 +607,25 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
       }
       const WsPlan w = plan(L);
       if (L.workspace_bytes < w.total + 255) return SOW_ERR_WORKSPACE;
+      void* dh = ws_base(L.workspace) + w.off_dh;
       if (group_chain_params(L, true, dtype, w, &batch[nb])) {
         if (++nb == C2_MAXG) {
           if ((rc = launch_chain2_group(batch, nb, true, stream))) return rc;
           nb = 0;
         }
+      } else if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 && !sw_on(SW_NO_GROUPED) &&
+                 gemm2h_supported(L.dy, L.d_out, L.acc_down, L.d_out, true, L.B, L.d_out, L.A, L.r_live, L.dx, L.d_in, nullptr, dh,
+                                  L.T, L.d_in, L.d_out, L.r_live, dtype)) {
+        gbatch[ng] = Gemm2hArgs{L.dy, L.acc_down, L.B, L.A, L.dx, nullptr, dh, L.T, L.d_out, L.d_out, L.d_out, L.r_live, L.d_in,
+                                L.d_in, L.d_out, L.r_live, L.scale};
+        if (++ng == 4) {
+          if ((rc = launch_gemm2h_group(gbatch, ng, true, stream))) return rc;
+          ng = 0;
+        }
       } else if ((rc = single(L, SOW_BWD_DATA)))
         return rc;
     }
+    if (ng && (rc = launch_gemm2h_group(gbatch, ng, true, stream))) return rc;
     if (nb && (rc = launch_chain2_group(batch, nb, true, stream))) return rc;
   }
   if (do_partial) {
@@ -713,6 +740,38 @@ int sow_qr_thin(const void* W, int64_t ldw, int m, int n, int in_dtype, int k, v
     }
   }
   return SOW_OK;
+}
+
+int sow_accumulate_batch(const sow_accumulate_args* items, int n, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!items) return SOW_ERR_NULL;
+  std::vector<AccItem> its((size_t)n);
+  std::vector<void*> zp;
+  std::vector<int64_t> zb;
+  for (int i = 0; i < n; ++i) {
+    const sow_accumulate_args& a = items[i];
+    if (a.d_in <= 0 || a.d_out <= 0 || a.r <= 0 || a.r > 64) return SOW_ERR_SHAPE;
+    if (!a.acc || !a.A || !a.B) return SOW_ERR_NULL;
+    AccItem& t = its[(size_t)i];
+    t.acc = a.acc, t.A = a.A, t.B = a.B, t.draw = a.draw, t.A_new = a.A_new, t.ld_draw = a.ld_draw;
+    t.d_in = a.d_in, t.d_out = a.d_out, t.r = a.r, t.r_new = a.r_new, t.scale = a.scale, t.beta = a.acc_beta;
+    t.Pt = t.Qt = nullptr, t.kc = 0;
+    if (a.draw) {
+      if (!a.A_new || !a.workspace || a.r_new <= 0 || a.r_new > a.d_in || a.draw_cols <= 0 || a.ld_draw < a.draw_cols)
+        return a.A_new && a.workspace ? SOW_ERR_SHAPE : SOW_ERR_NULL;
+      const QrPlan q = plan_qr(a.d_in, a.draw_cols, a.r_new, dtype, 0, 0);
+      if (a.workspace_bytes < q.total + 255) return SOW_ERR_WORKSPACE;
+      char* ws = ws_base(a.workspace);
+      t.kc = q.kc, t.Pt = (float*)(ws + q.off_pt), t.Qt = (float*)(ws + q.off_qt);
+    }
+    if (a.zero && a.zero_bytes > 0) zp.push_back(a.zero), zb.push_back(a.zero_bytes);
+  }
+  int rc = launch_accumulate_batch(its.data(), n, dtype, stream);
+  if (rc) return rc;
+  return zp.empty() ? SOW_OK : launch_multi_zero(zp.data(), zb.data(), (int)zp.size(), stream);
 }
 
 int sow_zero_state(void* const* ptrs, const int64_t* bytes, int n, void* stream) {

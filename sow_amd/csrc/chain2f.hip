@@ -334,7 +334,8 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += bv[e];
       }
-      *(f32x4*)dst = o;
+      // streaming store (see chain2.hip): Y is not re-read here; keeps the L2s clean for the end-of-kernel write-back
+      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
     }
   };
 #pragma unroll 1

@@ -138,6 +138,14 @@ enum Switch : int {
 int sw(int which);
 inline bool sw_on(int which) { return sw(which) > 0; }
 
+// streaming-store policy of the GEMM epilogues: outputs of tall products (activations, activation gradients) are not
+// re-read by the kernel that writes them
+#ifdef SOW_GEMM_NO_NT
+#define SOW_GEMM_NT(M) false
+#else
+#define SOW_GEMM_NT(M) ((M) >= 8192)
+#endif
+
 #define SOW_CHECK_LAUNCH()                     \
   do {                                         \
     hipError_t e__ = hipGetLastError();        \

@@ -22,7 +22,7 @@ template <int NT> struct EpiScratch {
 template <typename T, int NT, bool VEC>
 __device__ __forceinline__ void wave_store_tiles(const f32x16* acc, float* scratch, T* out, int64_t ld, int64_t row0,
                                                  int col0, int64_t M, int N, float alpha, float beta,
-                                                 const T* bias, int lane) {
+                                                 const T* bias, int lane, bool nt = false) {
   constexpr int W = EpiScratch<NT>::W, LD = EpiScratch<NT>::LD, VE = DT<T>::VE;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -66,7 +66,10 @@ __device__ __forceinline__ void wave_store_tiles(const f32x16* acc, float* scrat
         T* pe = (T*)&pk;
 #pragma unroll
         for (int j = 0; j < VE; ++j) pe[j] = from_f32<T>(v[j]);
-        *(u32x4*)dst = pk;
+        // nt: streaming (non-temporal) store for outputs the kernel never re-reads -- keeps the L2s clean, so the
+        // write-back at the end of the kernel has nothing left to do (see chain2.hip)
+        if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(pk) : "memory");
+        else *(u32x4*)dst = pk;
       }
     }
   } else {

@@ -207,7 +207,7 @@ template <bool NT> __global__ __launch_bounds__(G2_THREADS, 1) void gemm2_kernel
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
       wave_store_tiles<bf16_t, 2, true>(acc[mi], scratch, p.C, p.ldc, m0 + wm * 128 + mi * 32, n0 + wn * 64, M, N,
-                                        p.alpha, p.beta, p.bias, lane);
+                                        p.alpha, p.beta, p.bias, lane, SOW_GEMM_NT(M));
   }
 }
 

@@ -67,13 +67,28 @@ __device__ __forceinline__ void vm_wait_le(int n) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool NT> __global__ __launch_bounds__(GH_THREADS, 1) void gemm2h_kernel(const Gemm2hParams p) {
+// Grouped launch: the tile lists of up to GH_MAXG independent layers (q / k / v; gate / up) back to back in one grid --
+// every workgroup runs its own layer's tile unchanged (bit-identical results); prologue, epilogue and the write drain
+// of different workgroups overlap across the group instead of every layer paying its own launch ramp.
+constexpr int GH_MAXG = 4;
+struct Gemm2hGroup {
+  Gemm2hParams p[GH_MAXG];
+  int start[GH_MAXG + 1];
+  int n;
+};
+
+template <bool NT> __global__ __launch_bounds__(GH_THREADS, 1) void gemm2h_kernel(const Gemm2hGroup grp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 2, wn = w & 3, li = lane & 31, lh = lane >> 5;
+  int layer = 0;
+#pragma unroll
+  for (int i = 1; i < GH_MAXG; ++i)
+    if (i < grp.n && (int)blockIdx.x >= grp.start[i]) layer = i;
+  const Gemm2hParams& p = grp.p[layer];
   const int tiles_n = (p.N + GH_BN - 1) / GH_BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lid = xcd_remap((int)blockIdx.x - grp.start[layer], grp.start[layer + 1] - grp.start[layer]);
   const int64_t m0 = (int64_t)(lid / tiles_n) * GH_BM;
   const int n0 = (lid % tiles_n) * GH_BN;
   const int K = p.K, N = p.N, r = p.r;
@@ -344,7 +359,7 @@ template <bool NT> __global__ __launch_bounds__(GH_THREADS, 1) void gemm2h_kerne
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
       wave_store_tiles<bf16_t, 2, true>(acc[mi], scratch, p.C, p.ldc, m0 + wm * 128 + (mi ^ wn) * 32, n0 + wn * 64, M, N, 1.f,
-                                        0.f, p.bias, lane);
+                                        0.f, p.bias, lane, SOW_GEMM_NT(M));
   }
   if (tiles_n == 2 || n0 == 0) {
     // saved copy of h for the weight-gradient kernels, AFTER the C stores (hipcc guards the scratch reads above with
@@ -405,26 +420,40 @@ bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bo
   return true;
 }
 
-int launch_gemm2h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
-                  const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
-                  int r, float hscale, hipStream_t stream) {
-  Gemm2hParams p;
-  p.X = (const bf16_t*)X, p.W = (const bf16_t*)W, p.F = (const bf16_t*)F, p.G = (const bf16_t*)G;
-  p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias, p.H = (bf16_t*)H;
-  p.M = M, p.ldx = ldx, p.ldw = ldw, p.ldf = ldf, p.ldg = ldg, p.ldc = ldc;
-  p.N = N, p.K = K, p.r = r, p.hscale = hscale;
-  const int64_t tiles = (int64_t)ceil_div(M, GH_BM) * ceil_div(N, GH_BN);
-  if (tiles <= 0) return SOW_OK;
-  if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+int launch_gemm2h_group(const Gemm2hArgs* a, int n, bool nt, hipStream_t stream) {
+  if (n <= 0) return SOW_OK;
+  if (n > GH_MAXG) return SOW_ERR_SHAPE;
+  Gemm2hGroup g{};
+  g.n = n;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    Gemm2hParams& p = g.p[i];
+    p.X = (const bf16_t*)a[i].X, p.W = (const bf16_t*)a[i].W, p.F = (const bf16_t*)a[i].F, p.G = (const bf16_t*)a[i].G;
+    p.C = (bf16_t*)a[i].C, p.bias = (const bf16_t*)a[i].bias, p.H = (bf16_t*)a[i].H;
+    p.M = a[i].M, p.ldx = a[i].ldx, p.ldw = a[i].ldw, p.ldf = a[i].ldf, p.ldg = a[i].ldg, p.ldc = a[i].ldc;
+    p.N = a[i].N, p.K = a[i].K, p.r = a[i].r, p.hscale = a[i].hscale;
+    g.start[i] = (int)total;
+    total += (int64_t)ceil_div(p.M, GH_BM) * ceil_div(p.N, GH_BN);
+  }
+  for (int i = n; i <= GH_MAXG; ++i) g.start[i] = (int)total;
+  if (total <= 0) return SOW_OK;
+  if (total > 0x7fffffff) return SOW_ERR_SHAPE;
   if (nt) {
     SOW_SET_MAX_LDS_ONCE(GH_LDS, gemm2h_kernel<true>);
-    hipLaunchKernelGGL(gemm2h_kernel<true>, dim3((unsigned)tiles), dim3(GH_THREADS), GH_LDS, stream, p);
+    hipLaunchKernelGGL(gemm2h_kernel<true>, dim3((unsigned)total), dim3(GH_THREADS), GH_LDS, stream, g);
   } else {
     SOW_SET_MAX_LDS_ONCE(GH_LDS, gemm2h_kernel<false>);
-    hipLaunchKernelGGL(gemm2h_kernel<false>, dim3((unsigned)tiles), dim3(GH_THREADS), GH_LDS, stream, p);
+    hipLaunchKernelGGL(gemm2h_kernel<false>, dim3((unsigned)total), dim3(GH_THREADS), GH_LDS, stream, g);
   }
   SOW_CHECK_LAUNCH();
   return SOW_OK;
+}
+
+int launch_gemm2h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
+                  const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
+                  int r, float hscale, hipStream_t stream) {
+  const Gemm2hArgs a{X, W, F, G, C, bias, H, M, ldx, ldw, ldf, ldg, ldc, N, K, r, hscale};
+  return launch_gemm2h_group(&a, 1, nt, stream);
 }
 
 }  // namespace sow

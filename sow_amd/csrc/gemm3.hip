@@ -259,9 +259,9 @@ template <bool NT> __global__ __launch_bounds__(G3_THREADS, 1) void gemm3_kernel
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       wave_store_tiles<bf16_t, 2, true>(&acc[mi][0], scratch, p.C, p.ldc, m0 + wm * 128 + mi * 32, n0 + wn * 128, M, N, p.alpha,
-                                        p.beta, p.bias, lane);
+                                        p.beta, p.bias, lane, SOW_GEMM_NT(M));
       wave_store_tiles<bf16_t, 2, true>(&acc[mi][2], scratch, p.C, p.ldc, m0 + wm * 128 + mi * 32, n0 + wn * 128 + 64, M, N,
-                                        p.alpha, p.beta, p.bias, lane);
+                                        p.alpha, p.beta, p.bias, lane, SOW_GEMM_NT(M));
     }
   }
 }

@@ -271,7 +271,7 @@ template <bool NT> __global__ __launch_bounds__(GS_THREADS, 1) void gemm3s_kerne
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
       wave_store_tiles<bf16_t, 2, true>(&acc[mi][0], scratch, p.C, p.ldc, m0 + wm * 64 + mi * 32, n0 + wn * 64, M, N, p.alpha,
-                                        p.beta, p.bias, lane);
+                                        p.beta, p.bias, lane, SOW_GEMM_NT(M));
   }
 }
 

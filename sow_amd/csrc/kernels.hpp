@@ -120,6 +120,16 @@ bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bo
 int launch_gemm2h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
                   const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
                   int r, float hscale, hipStream_t stream);
+struct Gemm2hArgs {   // the arguments of launch_gemm2h for one layer of a grouped launch (same nt for the whole group)
+  const void *X, *W, *F, *G;
+  void* C;
+  const void* bias;
+  void* H;
+  int64_t M, ldx, ldw, ldf, ldg, ldc;
+  int N, K, r;
+  float hscale;
+};
+int launch_gemm2h_group(const Gemm2hArgs* a, int n, bool nt, hipStream_t stream);   // n <= 4, every layer gemm2h_supported
 // gemm3s.hip (same contract; 128x128 tiles for products with few 256x256 tiles: short M)
 int launch_gemm3s(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                   const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
@@ -131,6 +141,25 @@ int launch_qr_panel(const void* W, int64_t ldw, int in_dtype, int m, int kc, int
                     hipStream_t stream);
 int launch_qr_copy_out(const float* Qt, const float* Pt, void* Q, int64_t ldq, void* R, int64_t ldr, int out_dtype, int m,
                        int kc, int r, int k_rows, hipStream_t stream);
+// accumulate.hip: the periodic step of many layers, one launch per phase
+struct AccItem {
+  void* acc;            // [d_in, d_out] dense accumulator, acc = beta * acc + scale * A . B
+  const void* A;        // [d_in, r]
+  const void* B;        // [r, d_out]
+  const void* draw;     // [d_in, >= kc] Gaussian draw (row stride ld_draw) or nullptr: no re-initialisation
+  void* A_new;          // [d_in, r_new] <- Q[:, :r_new] of the draw (may alias A)
+  float* Pt;            // workspace: kc * d_in floats
+  float* Qt;            // workspace: r_new * d_in floats
+  int64_t ld_draw;
+  int d_in, d_out, r, r_new, kc;
+  float scale, beta;
+};
+constexpr int ACC_MAXB = 48;   // layers per launch (kernel-argument block of 48 x 80 bytes)
+struct AccBatch {
+  AccItem it[ACC_MAXB];
+  int n;
+};
+int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t stream);
 // misc.hip
 int launch_multi_zero(void* const* ptrs, const int64_t* bytes, int n, hipStream_t stream);
 int launch_adamw_flat(void* p, const void* g, void* m, void* v, int64_t n, float lr, float b1, float b2, float eps,

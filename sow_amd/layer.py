@@ -103,6 +103,8 @@ class SoWLinear(nn.Module):
         w = torch.zeros(shape, device=device, dtype=dtype)
         return nn.init.normal_(w, mean=0.0, std=0.02)  # std hard-coded as in sow.py:96 / :169
 
+    _fresh_gaussian_default = _fresh_gaussian   # lets the batched accumulate see whether a test has replaced the draw
+
     def reset_parameters(self, reset_scale=1.0) -> None:
         """sow.py:89-105.  normal_QR: A = Q[:, :r], B = R[:r, :] of the QR of an fp32 N(0, 0.02^2)
         [in, out] draw (the reference draws it on "cuda", :91 -- here on the factors' GPU)."""

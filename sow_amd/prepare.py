@@ -149,9 +149,93 @@ def accumulate(model):
     buckets = {id(s.bucket): s.bucket for s in (getattr(m, "_grad_sink", None) for m in mods) if s is not None}
     for b in buckets.values():
         b.finalize()
-    _accumulate_layers(mods)
+    fast = [m for m in mods if _batchable(m)]
+    if len(fast) >= 2:
+        _accumulate_batched(fast)
+        slow = [m for m in mods if not _batchable_cached.pop(id(m), False)]
+    else:
+        _batchable_cached.clear()
+        slow = mods
+    _accumulate_layers(slow)
     for b in buckets.values():
         b.rebind()
+
+
+_batchable_cached: dict = {}
+
+
+def _batchable(m) -> bool:
+    """Layers the batched entry point covers: one factor pair, r <= 64, on the GPU, on the dense-accumulator branch of
+    sow.py:144-153 (what prepare_sow sets up, prepare.py:120) with no low-rank accumulator left to materialise."""
+    A = m.downscale_weights._parameters["0"] if m.n_iter == 1 else None
+    ok = (A is not None and A.is_cuda and m.rank <= 64 and m.virtual_rank >= min(m.in_features, m.out_features)
+          and m.acc_upweight.numel() == 0 and A.dtype in ops._DT and A.is_contiguous()
+          and m.upscale_weights._parameters["0"].is_contiguous()
+          and (m.acc_downweight.numel() == 0 or (m.acc_downweight.dtype == A.dtype and m.acc_downweight.is_contiguous()
+                                                 and m.acc_downweight.device == A.device)))
+    _batchable_cached[id(m)] = ok
+    return ok
+
+
+def _accumulate_batched(mods):
+    """sow.py:128-178 for many layers through ONE C call (sow_accumulate_batch: one launch per phase for all of them).
+
+    In-place where the reference rebinds: the dense accumulator is updated where it lives, the new orthonormal A and the
+    zeroed B are written into the parameters' own storage (after the update has consumed the old factors -- stream
+    order), so optimizer references, flat-bucket views and allocator state are untouched.  Only the first `rank`
+    columns of the [in, out] Gaussian of sow.py:163-171 reach Q[:, :rank], so unless a test has hooked the draw
+    (`_fresh_gaussian`), only those columns are drawn -- one normal_() launch for the whole model."""
+    import ctypes
+
+    from . import _lib
+    lib = _lib.load()
+    dev = mods[0].downscale_weights._parameters["0"].device
+    by_dtype = {}
+    for m in mods:
+        by_dtype.setdefault(m.downscale_weights._parameters["0"].dtype, []).append(m)
+    for dtype, group in by_dtype.items():
+        es = 2 if dtype == torch.bfloat16 else 4
+        hooked = [("_fresh_gaussian" in m.__dict__) or (type(m)._fresh_gaussian is not SoWLinear._fresh_gaussian_default)
+                  for m in group]
+        qr = [m.init_method == "normal_QR" for m in group]
+        # Gaussian draws for the re-initialisation, in the accumulator's dtype as in sow.py:163-165
+        n_flat = sum(m.in_features * m.rank for m, h in zip(group, hooked) if not h)
+        flat = torch.empty(n_flat, device=dev, dtype=dtype).normal_(mean=0.0, std=0.02) if n_flat else None
+        draws, off = [], 0
+        for m, h, q in zip(group, hooked, qr):
+            if h:
+                shape = (m.in_features, m.out_features) if q else (m.in_features, m.rank)
+                draws.append(m._fresh_gaussian(shape, dev, dtype).to(dtype).contiguous())
+            else:
+                draws.append(flat[off:off + m.in_features * m.rank].view(m.in_features, m.rank))
+                off += m.in_features * m.rank
+        ws_sizes = [((int(lib.sow_qr_workspace_bytes(m.in_features, d.shape[1], m.rank, ops._DT[dtype], 0)) + 255) // 256 * 256) if q else 0
+                    for m, d, q in zip(group, draws, qr)]
+        ws = torch.empty(sum(ws_sizes) + 256, device=dev, dtype=torch.uint8)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        arr = (_lib.AccumulateArgs * len(group))()
+        keep, off = [], 0
+        for i, (m, d, q) in enumerate(zip(group, draws, qr)):
+            A, B = m.downscale_weights._parameters["0"].data, m.upscale_weights._parameters["0"].data
+            if m.acc_downweight.numel():
+                acc, beta = m.acc_downweight.data, 1.0
+            else:
+                acc, beta = torch.empty(m.in_features, m.out_features, device=dev, dtype=dtype), 0.0
+                m.acc_downweight = nn.Parameter(acc, requires_grad=False)
+                m.acc_upweight = nn.Parameter(torch.empty(0, device=dev), requires_grad=False)
+            keep.append((A, B, acc, d))
+            a = arr[i]
+            a.acc, a.A, a.B = acc.data_ptr(), A.data_ptr(), B.data_ptr()
+            a.draw, a.ld_draw, a.draw_cols = (d.data_ptr(), d.stride(0), d.shape[1]) if q else (None, 0, 0)
+            a.A_new, a.zero, a.zero_bytes = A.data_ptr(), B.data_ptr(), B.numel() * es
+            a.d_in, a.d_out, a.r, a.r_new = m.in_features, m.out_features, m.rank, m.rank
+            a.scale, a.acc_beta = float(m.scale), beta
+            a.workspace, a.workspace_bytes = (ws_ptr + off, ws_sizes[i]) if q else (None, 0)
+            off += ws_sizes[i]
+        ops._launch(dev, "sow_accumulate_batch", lib.sow_accumulate_batch, arr, len(group), ops._DT[dtype])
+        for (A, _, _, d), q in zip(keep, qr):
+            if not q:                       # plain Gaussian re-initialisation (sow.py:174): after the update has read A
+                A.copy_(d)
 
 
 def _accumulate_layers(mods):

@@ -359,7 +359,7 @@ def test_tt_newton_and_reciprocal_vs_reference():
 # ---------------------------------------------------------------------------------------------
 # grouped C-ABI calls (sow_forward_group / sow_backward_group)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["qkv", "gate_up", "mixed"])
+@pytest.mark.parametrize("case", ["qkv", "gate_up", "mixed", "dense_qkv"])
 def test_grouped_calls_are_bit_identical_to_single_calls(case):
     """{q, k, v} / {gate, up} of a decoder block in ONE grid per kernel: outputs, saved h, dX, dA, dB bit-identical to the
     per-layer calls (every workgroup runs the single-layer code on its own layer).  `mixed`: an eligible layer next to a
@@ -370,6 +370,9 @@ def test_grouped_calls_are_bit_identical_to_single_calls(case):
         specs = [(T, 512, 512, 50, False)] * 3
     elif case == "gate_up":
         specs = [(T, 512, 1376, 50, False), (T, 512, 1376, 50, False)]
+    elif case == "dense_qkv":   # dense accumulator: the one-launch-per-layer GEMM (gemm2h) shares its grid across the group
+        T = 20600
+        specs = [(T, 512, 512, 50, True)] * 3 + [(T, 1376, 512, 50, True)]
     else:
         specs = [(T, 512, 512, 50, False), (T, 512, 512, 50, True), (4096, 512, 1376, 50, False), (T, 264, 72, 34, False),
                  (T, 1376, 512, 50, False)]
@@ -405,3 +408,84 @@ def test_grouped_calls_are_bit_identical_to_single_calls(case):
         grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
     for c, (y1, _, dx1, dA1, _) in zip(calls, singles):
         assert torch.equal(c.y, y1) and torch.equal(c.dx, dx1) and torch.equal(c._keep[7], dA1)
+
+
+# ---------------------------------------------------------------------------------------------
+# batched periodic step (sow_accumulate_batch)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("init", ["normal_QR", "normal"])
+def test_accumulate_model_batched_equals_per_layer(dtype, init):
+    """accumulate(model) -- one C call, one launch per phase for all layers -- against SoWLinear.accumulate() layer by
+    layer on an identical copy with the same re-initialisation draws: accumulator, new A (orthonormal, LAPACK signs),
+    zeroed B; first call (no accumulator yet) and second call (in-place update); a layer the batch does not cover
+    (n_iter = 2) takes the per-layer path inside the same call."""
+    import copy
+
+    from sow_amd import SoWLinear, accumulate
+    torch.manual_seed(3)
+    shapes = [(512, 512), (512, 1376), (1376, 512), (96, 40), (200, 264)]
+    net = nn.ModuleList([SoWLinear(i, o, bias=False, rank=r, scale=0.5, init_method="normal", device=DEV, dtype=dtype)
+                         for (i, o), r in zip(shapes, (50, 50, 50, 8, 34))])
+    net.append(SoWLinear(64, 48, bias=False, rank=4, n_iter=2, scale=0.5, init_method="normal", device=DEV, dtype=dtype))
+    for m in net:
+        m.init_method = init
+        m.virtual_rank = min(m.in_features, m.out_features)          # what prepare_sow sets (prepare.py:120)
+    ref = copy.deepcopy(net)
+    gen = torch.Generator().manual_seed(5)
+    for call in range(2):
+        for m, mr in zip(net, ref):
+            for i in range(m.n_iter):
+                b = (torch.randn(m.rank, m.out_features, generator=gen) * 0.1).to(DEV, dtype)
+                m.upscale_weights[i].data.copy_(b)
+                mr.upscale_weights[i].data.copy_(b)
+            shape = (m.in_features, m.out_features) if init == "normal_QR" else (m.in_features, m.rank)
+            ds = [torch.randn(*shape, generator=gen) * 0.02 for _ in range(m.n_iter)]
+            for mod in (m, mr):
+                mod._fresh_gaussian = lambda shape, device, dtype_, _it=iter(ds): next(_it).to(device, dtype_)
+        pA = net[0].downscale_weights[0].data.data_ptr()
+        accumulate(net)                       # batched (layers 0-4) + per-layer (layer 5)
+        for mr in ref:
+            mr.accumulate()
+        torch.cuda.synchronize()
+        assert net[0].downscale_weights[0].data.data_ptr() == pA       # factors rewritten in place
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        qtol = 5e-5 if dtype == torch.float32 else 2e-2
+        for m, mr in zip(net, ref):
+            assert tuple(m.acc_downweight.shape) == (m.in_features, m.out_features) and m.acc_upweight.numel() == 0
+            assert m.virtual_rank == mr.virtual_rank
+            assert rel_err(m.acc_downweight.float().cpu(), mr.acc_downweight.float().cpu()) < tol, (call, m.in_features)
+            for i in range(m.n_iter):
+                assert rel_err(m.downscale_weights[i].data.float().cpu(), mr.downscale_weights[i].data.float().cpu()) < qtol
+                assert float(m.upscale_weights[i].data.abs().max()) == 0.0
+        if init == "normal_QR" and dtype == torch.float32:
+            q = net[1].downscale_weights[0].data.double()
+            assert float((q.t() @ q - torch.eye(50, device=DEV, dtype=torch.float64)).abs().max()) < 1e-5
+
+
+def test_accumulate_llama60m_unhooked_draws_are_orthonormal_and_fast():
+    """The production path (no draw hook): one normal_() for all layers, only the first `rank` columns drawn."""
+    import time
+
+    from sow_amd import SoWLinear, accumulate
+    torch.manual_seed(0)
+    shapes = ([(512, 512)] * 4 + [(512, 1376)] * 2 + [(1376, 512)]) * 8
+    net = nn.ModuleList([SoWLinear(i, o, bias=False, rank=50, init_method="normal", device=DEV, dtype=torch.bfloat16) for i, o in shapes])
+    for m in net:
+        m.init_method = "normal_QR"
+        m.virtual_rank = min(m.in_features, m.out_features)
+    accumulate(net)
+    accumulate(net)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    accumulate(net)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    for m in (net[0], net[4], net[6], net[55]):
+        q = m.downscale_weights[0].data.double()
+        assert float((q.t() @ q - torch.eye(50, device=DEV, dtype=torch.float64)).abs().max()) < 2e-2
+        assert float(m.upscale_weights[0].data.abs().max()) == 0.0
+    different = float((net[0].downscale_weights[0].data.float() - net[1].downscale_weights[0].data.float()).abs().max())
+    assert different > 1e-3          # independent draws per layer
+    print(f"accumulate(llama_60m, 56 layers): {ms:.2f} ms")
+    assert ms < 10.0
