@@ -79,6 +79,10 @@ def parse():
                     help="weight-gradient partial sums: one launch per decoder block (7 layers, after the block's data-gradient "
                          "kernels) or one per launch group, right after that group's data-gradient kernel (dY still in the "
                          "Infinity Cache)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: the weight-gradient launches (one per decoder block) go to a side stream forked from the block's last "
+                         "data-gradient kernel and joined before the batched reduction, so their start overlaps the write drain "
+                         "of the data-gradient kernels")
     ap.add_argument("--group", choices=["block", "none"], default="block",
                     help="block: {q,k,v} and {gate,up} of a decoder block share launches (grouped C-ABI calls); none: one call per layer")
     return ap.parse_args()
@@ -87,11 +91,12 @@ def parse():
 class Stack:
     """The 56-layer SoWLinear stack with resident synthetic inputs and static output buffers."""
 
-    def __init__(self, shapes, T, r, dtype, device, acc, reduce="batch", group="block", tn_group="block"):
+    def __init__(self, shapes, T, r, dtype, device, acc, reduce="batch", group="block", tn_group="block", streams=1):
         from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
         self.deferred = ops.DeferredReduce() if reduce == "batch" else None
+        self.side = torch.cuda.Stream(device=device) if streams > 1 else None
         kind = 2 if acc == "dense" else 0
         g = torch.Generator(device=device)
         self.x, self.dy, self.A, self.B, self.W = [], [], [], [], []
@@ -145,12 +150,21 @@ class Stack:
                 self.groups[gi].backward(_lib.BWD_DATA)
             ti = first_of_block.get(gi)        # the block's first group is its last in backward order: then its weights
             if ti is not None and (full or (phases == _lib.BWD_WEIGHTS_PARTIAL and (tn_only is None or ti in tn_only))):
-                self.tn_groups[ti].backward(_lib.BWD_WEIGHTS_PARTIAL if (self.deferred is not None or not full) else _lib.BWD_WEIGHTS)
+                tn_ph = _lib.BWD_WEIGHTS_PARTIAL if (self.deferred is not None or not full) else _lib.BWD_WEIGHTS
+                if self.side is not None and full:
+                    main = torch.cuda.current_stream()
+                    self.side.wait_stream(main)          # after this block's data-gradient kernels (they produce dh)
+                    with torch.cuda.stream(self.side):
+                        self.tn_groups[ti].backward(tn_ph)
+                else:
+                    self.tn_groups[ti].backward(tn_ph)
                 if self.deferred is not None and full:
                     for li in reversed(self.tn_layers[ti]):
                         c = self.calls[li]
                         self.deferred.add(self.x[li], self.B[li].data, (self.A[li].grad, self.B[li].grad, None), 0.0, c.workspace,
                                           self.W[li], None)
+        if self.side is not None and full:
+            torch.cuda.current_stream().wait_stream(self.side)
         if self.deferred is not None and full:
             self.deferred.run()
 
@@ -375,7 +389,7 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
     es = 2 if dtype_name == "bf16" else 4
     shapes = layer_shapes()
     T = args.tokens
-    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group, args.tn_group)
+    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group, args.tn_group, args.streams)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
 
@@ -523,7 +537,7 @@ def main():
             "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
                        "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": head["graph"],
-                       "weight_grad_reduce": args.reduce,
+                       "weight_grad_reduce": args.reduce, "streams": args.streams,
                        "launch_grouping": ("per decoder block: {q,k,v} {o} {gate,up} {down} for the chain kernels, all 7 layers for the "
                                            "weight-gradient partial sums; resident (persistent) workgroups") if args.group == "block" else "one call per layer"},
             "gflops": head["flops"] * world / (ms * 1e-3) / 1e9,

@@ -59,7 +59,12 @@ constexpr int C3_THREADS = 64 * (C3_NCW + C3_NLW);
 constexpr int C3_PARK0 = 32768;        // wave-private Y tiles live behind the 32-KiB exchange area
 
 
-template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_kernel(const ChainParams p) {
+// X3 = true: both products on the bf16 matrix pipe as 3 x bf16 splits (lds_dma.hpp: split3 / mfma_x3) -- fp32 accuracy
+// (the dropped cross terms are <= 2^-23 of each product) at 6 x 32 cycles per 16 k instead of 8 x 64, and, unlike the
+// fp32 MFMA, without blocking the other instructions of the SIMD.  Operand fragments are split in registers right
+// after they are read (11 VALU instructions per pair of elements).  X3 = false: the exact v_mfma_f32_32x32x2_f32 form
+// (F32_EXACT switch; the reference of the A/B test).
+template <bool BWD, bool X3> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_kernel(const ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -189,6 +194,57 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
     if (st + C3_DEPTH - 1 < nst) issue_x(st + C3_DEPTH - 1);   // into the slot of stage st-1
     const uint32_t xs = ring_a + (uint32_t)((st % C3_DEPTH) * C3_STAGE) + xrow;
     const uint32_t fs = slot_a + (uint32_t)((st % C3_NSLOT) * C3_FSLOT);
+    if constexpr (X3) {
+      // two k-steps of 16: lane-half lh multiplies k = 32 hh + 16 s + 8 lh + j, j = 0 .. 7
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f32x4 xa, xb, fa[2], fb[2];
+        const int c0 = 8 * hh + 4 * s2 + 2 * lh;   // first 16-byte chunk of this lane's 8 k
+        DS_READ_B128(xa, xs + (uint32_t)(((c0) ^ xsw) * 16), 0);
+        DS_READ_B128(xb, xs + (uint32_t)(((c0 + 1) ^ xsw) * 16), 0);
+        if constexpr (BWD) {
+          const uint32_t fr = fs + (uint32_t)(li * 256);
+          DS_READ_B128(fa[0], fr + (uint32_t)(((c0) ^ xsw) * 16), 0);
+          DS_READ_B128(fb[0], fr + (uint32_t)(((c0 + 1) ^ xsw) * 16), 0);
+          DS_READ_B128(fa[1], fr + (uint32_t)(((c0) ^ xsw) * 16), 32 * 256);
+          DS_READ_B128(fb[1], fr + (uint32_t)(((c0 + 1) ^ xsw) * 16), 32 * 256);
+        } else {
+          const uint32_t fr = fs + (uint32_t)((32 * hh + 16 * s2 + 8 * lh) * 256 + li * 4);
+          DS_READ_B32(fa[0][0], fr, 0 * 256);
+          DS_READ_B32(fa[0][1], fr, 1 * 256);
+          DS_READ_B32(fa[0][2], fr, 2 * 256);
+          DS_READ_B32(fa[0][3], fr, 3 * 256);
+          DS_READ_B32(fb[0][0], fr, 4 * 256);
+          DS_READ_B32(fb[0][1], fr, 5 * 256);
+          DS_READ_B32(fb[0][2], fr, 6 * 256);
+          DS_READ_B32(fb[0][3], fr, 7 * 256);
+          DS_READ_B32(fa[1][0], fr, 0 * 256 + 128);
+          DS_READ_B32(fa[1][1], fr, 1 * 256 + 128);
+          DS_READ_B32(fa[1][2], fr, 2 * 256 + 128);
+          DS_READ_B32(fa[1][3], fr, 3 * 256 + 128);
+          DS_READ_B32(fb[1][0], fr, 4 * 256 + 128);
+          DS_READ_B32(fb[1][1], fr, 5 * 256 + 128);
+          DS_READ_B32(fb[1][2], fr, 6 * 256 + 128);
+          DS_READ_B32(fb[1][3], fr, 7 * 256 + 128);
+        }
+        LGKM_WAIT0();
+        u32x4 xp[3], fp[2][3];
+        split3v(xa[0], xa[1], xp, 0);
+        split3v(xa[2], xa[3], xp, 1);
+        split3v(xb[0], xb[1], xp, 2);
+        split3v(xb[2], xb[3], xp, 3);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          split3v(fa[tl][0], fa[tl][1], fp[tl], 0);
+          split3v(fa[tl][2], fa[tl][3], fp[tl], 1);
+          split3v(fb[tl][0], fb[tl][1], fp[tl], 2);
+          split3v(fb[tl][2], fb[tl][3], fp[tl], 3);
+        }
+        hacc[0] = mfma_x3(fp[0], xp, hacc[0]);
+        hacc[1] = mfma_x3(fp[1], xp, hacc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     // four groups of 8 MFMAs (k = 32 hh + 8 m + 4 lh + j); the operands of group m+1 are fetched while
     // group m multiplies (double-buffered, counted lgkmcnt)
     f32x4 xf[2];
@@ -230,6 +286,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
         hacc[1] = mfma32(fq[m & 1][1][j], xf[m & 1][j], hacc[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -304,6 +361,15 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
   }
   }
   // ================================================================== phase 2: Y^T = F2^T . H^T (column tile hh)
+  [[maybe_unused]] u32x4 hp[4][3];   // X3: H^T as the B operand of k-step s, split once
+  [[maybe_unused]] const int ksteps = (rb + 15) / 16;
+  if constexpr (X3) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr)
+        split3v(hacc[s4 >> 1][8 * (s4 & 1) + 2 * pr], hacc[s4 >> 1][8 * (s4 & 1) + 2 * pr + 1], hp[s4], pr);
+  }
   float* Y = (float*)p.Y;
   const float* bias = (const float*)p.bias;
   const int nq = (rb + 7) / 8;
@@ -348,6 +414,41 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
     f32x16 yacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) yacc[i] = 0.f;
+    if constexpr (X3) {
+      // k-step s contracts ranks 16 s + 8 (j >> 2) + 4 lh + (j & 3), j = 0 .. 7 -- the order in which H^T's accumulator
+      // registers hold them (hp[s] was split once, after the hand-off)
+      if (sl > 0) flush_read();
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 < ksteps) {
+          f32x4 fa, fb;
+          if constexpr (BWD) {
+            const uint32_t fr = fs + (uint32_t)((hh * 32 + li) * 256);
+            DS_READ_B128(fa, fr + (uint32_t)(((4 * s4 + lh) ^ xsw) * 16), 0);
+            DS_READ_B128(fb, fr + (uint32_t)(((4 * s4 + 2 + lh) ^ xsw) * 16), 0);
+          } else {
+            const uint32_t fr = fs + (uint32_t)((16 * s4 + 4 * lh) * 256 + (hh * 32 + li) * 4);
+            DS_READ_B32(fa[0], fr, 0 * 256);
+            DS_READ_B32(fa[1], fr, 1 * 256);
+            DS_READ_B32(fa[2], fr, 2 * 256);
+            DS_READ_B32(fa[3], fr, 3 * 256);
+            DS_READ_B32(fb[0], fr, 8 * 256);
+            DS_READ_B32(fb[1], fr, 9 * 256);
+            DS_READ_B32(fb[2], fr, 10 * 256);
+            DS_READ_B32(fb[3], fr, 11 * 256);
+          }
+          LGKM_WAIT0();
+          u32x4 f2p[3];
+          split3v(fa[0], fa[1], f2p, 0);
+          split3v(fa[2], fa[3], f2p, 1);
+          split3v(fb[0], fb[1], f2p, 2);
+          split3v(fb[2], fb[3], f2p, 3);
+          yacc = mfma_x3(f2p, hp[s4], yacc);
+        }
+        if (sl > 0) flush_store(sl - 1, s4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     f32x4 fq[2];
     auto fetch2 = [&](int q, int bsel) {
       if constexpr (BWD) {
@@ -390,6 +491,7 @@ template <bool BWD> __global__ __launch_bounds__(C3_THREADS, 4) void chain2f_ker
           if (q >= nq) flush_store(sl - 1, q);
       }
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     // park this slice: register quad rq holds columns 8 rq + 4 lh .. +3 of token li
 #pragma unroll
@@ -431,13 +533,13 @@ int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream) {
     const int nsplit = p.st_per > 0 ? ceil_div((p.D1 + 63) / 64, p.st_per) : ceil_div((p.D2 + 63) / 64, p.sl_per);
     grid = p.ntb * nsplit;
   }
-  if (bwd) {
-    SOW_SET_MAX_LDS_ONCE(C3_LDS, chain2f_kernel<true>);
-    hipLaunchKernelGGL(chain2f_kernel<true>, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);
-  } else {
-    SOW_SET_MAX_LDS_ONCE(C3_LDS, chain2f_kernel<false>);
-    hipLaunchKernelGGL(chain2f_kernel<false>, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);
-  }
+  // commas of the template-id would split the macro argument: name the instantiations first
+  using KernelFn = void (*)(const ChainParams);
+  const bool x3 = !sw_on(SW_F32_EXACT);
+  const KernelFn k = bwd ? (x3 ? (KernelFn)chain2f_kernel<true, true> : (KernelFn)chain2f_kernel<true, false>)
+                         : (x3 ? (KernelFn)chain2f_kernel<false, true> : (KernelFn)chain2f_kernel<false, false>);
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }

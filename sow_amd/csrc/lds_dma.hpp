@@ -59,4 +59,39 @@ __device__ __forceinline__ void dma16_nt(const void* src, char* lds_dst) {
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0], lo[1], hi[0], hi[1]}; }
+// ---- fp32 on the bf16 matrix pipe ("3 x bf16"): x = hi + mid + lo with three bf16 values that hold the 24 mantissa bits
+// EXACTLY (truncation split: the residuals x - hi and x - hi - mid are exact in fp32), and
+//     a * b  ~=  ah bh + ah bm + am bh + am bm + ah bl + al bh          (fp32 accumulation in the MFMA)
+// drops only am bl + al bm + al bl <= 2^-23 |a b| -- below the rounding of one fp32 multiply-add.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each, 16 k) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each, 2 k): 2.7 x less
+// matrix-pipe time per product, and -- unlike the fp32 MFMA, which blocks every other instruction of its SIMD while
+// it runs (tools/probe4.hip) -- the bf16 MFMA lets LDS reads, VALU and DMA issue of the partner wave pass.
+// The price is the split: 11 VALU instructions per pair of operand elements.
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const uint32_t u0 = __builtin_bit_cast(uint32_t, x0), u1 = __builtin_bit_cast(uint32_t, x1);
+  const uint32_t h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
+  const float r0 = x0 - __builtin_bit_cast(float, h0), r1 = x1 - __builtin_bit_cast(float, h1);     // exact
+  const uint32_t m0 = __builtin_bit_cast(uint32_t, r0) & 0xffff0000u, m1 = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+  const float q0 = r0 - __builtin_bit_cast(float, m0), q1 = r1 - __builtin_bit_cast(float, m1);     // exact, <= 8 bits
+  h = (h0 >> 16) | h1;
+  m = (m0 >> 16) | m1;
+  l = (__builtin_bit_cast(uint32_t, q0) >> 16) | (__builtin_bit_cast(uint32_t, q1) & 0xffff0000u);
+}
+// element pair e (bf16 elements 2e, 2e + 1) of the three plane vectors of a fragment
+__device__ __forceinline__ void split3v(float x0, float x1, u32x4 (&pl)[3], int e) {
+  uint32_t h, m, l;
+  split3(x0, x1, h, m, l);
+  pl[0][e] = h, pl[1][e] = m, pl[2][e] = l;
+}
+// acc += a * b for fragments split into (hi, mid, lo) planes
+__device__ __forceinline__ f32x16 mfma_x3(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc) {
+  acc = mfma32(as_bf16x8(a[2]), as_bf16x8(b[0]), acc);   // small terms first
+  acc = mfma32(as_bf16x8(a[0]), as_bf16x8(b[2]), acc);
+  acc = mfma32(as_bf16x8(a[1]), as_bf16x8(b[1]), acc);
+  acc = mfma32(as_bf16x8(a[1]), as_bf16x8(b[0]), acc);
+  acc = mfma32(as_bf16x8(a[0]), as_bf16x8(b[1]), acc);
+  acc = mfma32(as_bf16x8(a[0]), as_bf16x8(b[0]), acc);
+  return acc;
+}
+
 }  // namespace sow

@@ -566,7 +566,10 @@ __global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(
 constexpr int TNF_DEPTH = 4;
 constexpr int TNF_STAGE_BYTES = 4096;       // [8][64] fp32 M tile + [8][64] fp32 S tile
 
-__global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnParams p) {
+// X3 = true: the 3 x bf16 form above -- a k-step is 16 tokens = TWO consecutive 8-token stages of this wave (lane-half lh
+// takes stage 2 q + lh; any 16 tokens will do, M and S use the same ones), accumulator layout unchanged.
+// X3 = false: the exact-fp32 MFMA form (kept behind the F32_EXACT switch: the reference for the A/B test).
+template <bool X3> __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -638,6 +641,57 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnPara
   const uint32_t lane_off = (uint32_t)(lh * 256 + li * 8);   // token row lh of a pair, columns 2 li, 2 li + 1
   const int pre = nw < TNF_DEPTH ? nw : TNF_DEPTH;
   for (int i = 0; i < pre; ++i) issue(i);
+  if constexpr (X3) {
+    const int npair = (nw + 1) / 2;
+    for (int q = 0; q < npair; ++q) {
+      const bool has1 = 2 * q + 1 < nw;   // wave-uniform: the second stage of the pair exists
+      const int last = has1 ? 2 * q + 1 : 2 * q;
+      const int issued = nw < 2 * q + TNF_DEPTH ? nw : 2 * q + TNF_DEPTH;
+      tn_wait_stages(issued - 1 - last);
+      __builtin_amdgcn_sched_barrier(0);
+      const int st = 2 * q + (has1 ? lh : 0);
+      const uint32_t ad = ring_addr + (uint32_t)((st % TNF_DEPTH) * TNF_STAGE_BYTES) + (uint32_t)(li * 8);
+      f32x2 mv[8], sv[8];
+      DS_READ_B64(mv[0], ad, 0 * 256);
+      DS_READ_B64(mv[1], ad, 1 * 256);
+      DS_READ_B64(mv[2], ad, 2 * 256);
+      DS_READ_B64(mv[3], ad, 3 * 256);
+      DS_READ_B64(mv[4], ad, 4 * 256);
+      DS_READ_B64(mv[5], ad, 5 * 256);
+      DS_READ_B64(mv[6], ad, 6 * 256);
+      DS_READ_B64(mv[7], ad, 7 * 256);
+      DS_READ_B64(sv[0], ad, 2048 + 0 * 256);
+      DS_READ_B64(sv[1], ad, 2048 + 1 * 256);
+      DS_READ_B64(sv[2], ad, 2048 + 2 * 256);
+      DS_READ_B64(sv[3], ad, 2048 + 3 * 256);
+      DS_READ_B64(sv[4], ad, 2048 + 4 * 256);
+      DS_READ_B64(sv[5], ad, 2048 + 5 * 256);
+      DS_READ_B64(sv[6], ad, 2048 + 6 * 256);
+      DS_READ_B64(sv[7], ad, 2048 + 7 * 256);
+      LGKM_WAIT0();
+      const bool dead = !has1 && lh == 1;   // odd tail: the upper lane-half has no tokens
+      u32x4 mp[2][3], sp[2][3];            // [column parity][plane]
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const float m0 = dead ? 0.f : mv[2 * pr][a], m1 = dead ? 0.f : mv[2 * pr + 1][a];
+          const float s0 = dead ? 0.f : sv[2 * pr][a], s1 = dead ? 0.f : sv[2 * pr + 1][a];
+          uint32_t h, m, l;
+          split3(m0, m1, h, m, l);
+          mp[a][0][pr] = h, mp[a][1][pr] = m, mp[a][2][pr] = l;
+          split3(s0, s1, h, m, l);
+          sp[a][0][pr] = h, sp[a][1][pr] = m, sp[a][2][pr] = l;
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = mfma_x3(mp[a], sp[c], acc[a][c]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (2 * q + TNF_DEPTH < nw) issue(2 * q + TNF_DEPTH);
+      if (2 * q + 1 + TNF_DEPTH < nw) issue(2 * q + 1 + TNF_DEPTH);
+    }
+  } else {
   for (int i = 0; i < nw; ++i) {
     const int newer = (nw - 1 - i) < (TNF_DEPTH - 1) ? (nw - 1 - i) : (TNF_DEPTH - 1);
     tn_wait_stages(newer);
@@ -670,6 +724,7 @@ __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_kernel(const TnPara
 #undef TNF_PAIR
     __builtin_amdgcn_sched_barrier(0);
     if (i + TNF_DEPTH < nw) issue(i + TNF_DEPTH);
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -883,8 +938,13 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
     }
     if (dma) {
       constexpr int LDS = 4 * TNF_DEPTH * TNF_STAGE_BYTES;  // 64 KiB
-      SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_f32_kernel);
-      hipLaunchKernelGGL(tn_partial_dma_f32_kernel, dim3(blocks), dim3(256), LDS, stream, p);
+      if (sw_on(SW_F32_EXACT)) {
+        SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_f32_kernel<false>);
+        hipLaunchKernelGGL(tn_partial_dma_f32_kernel<false>, dim3(blocks), dim3(256), LDS, stream, p);
+      } else {
+        SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_f32_kernel<true>);
+        hipLaunchKernelGGL(tn_partial_dma_f32_kernel<true>, dim3(blocks), dim3(256), LDS, stream, p);
+      }
     } else {
       hipLaunchKernelGGL(tn_partial_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
     }
