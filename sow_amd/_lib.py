@@ -116,15 +116,24 @@ class switch:
         self.values = values
         self.old = {}
 
+    @staticmethod
+    def _forget_sizes():
+        # workspace sizes depend on the kernel choice (slab counts): drop the memoised queries of sow_amd.ops
+        from . import ops
+        ops._WS_BYTES.clear()
+        ops._FWD_WS_BYTES.clear()
+
     def __enter__(self):
         lib = load()
         for k, v in self.values.items():
             self.old[k] = lib.sow_get_switch(k.encode())
             check(lib.sow_set_switch(k.encode(), int(v)), f"sow_set_switch({k})")
+        self._forget_sizes()
         return self
 
     def __exit__(self, *exc):
         lib = load()
         for k, v in self.old.items():
             lib.sow_set_switch(k.encode(), v)
+        self._forget_sizes()
         return False

@@ -68,14 +68,18 @@ __device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0
 // it runs (tools/probe4.hip) -- the bf16 MFMA lets LDS reads, VALU and DMA issue of the partner wave pass.
 // The price is the split: 11 VALU instructions per pair of operand elements.
 __device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  // 9 VALU instructions per pair: 2 masks + 1 packed subtract per level, one v_perm_b32 per plane to pack the high halves
+  constexpr uint32_t HI = 0x07060302u;   // v_perm_b32(b, a, HI) = (a >> 16) | (b & 0xffff0000)
   const uint32_t u0 = __builtin_bit_cast(uint32_t, x0), u1 = __builtin_bit_cast(uint32_t, x1);
-  const uint32_t h0 = u0 & 0xffff0000u, h1 = u1 & 0xffff0000u;
-  const float r0 = x0 - __builtin_bit_cast(float, h0), r1 = x1 - __builtin_bit_cast(float, h1);     // exact
-  const uint32_t m0 = __builtin_bit_cast(uint32_t, r0) & 0xffff0000u, m1 = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-  const float q0 = r0 - __builtin_bit_cast(float, m0), q1 = r1 - __builtin_bit_cast(float, m1);     // exact, <= 8 bits
-  h = (h0 >> 16) | h1;
-  m = (m0 >> 16) | m1;
-  l = (__builtin_bit_cast(uint32_t, q0) >> 16) | (__builtin_bit_cast(uint32_t, q1) & 0xffff0000u);
+  h = __builtin_amdgcn_perm(u1, u0, HI);
+  const f32x2 x = {x0, x1};
+  const f32x2 hf = {__builtin_bit_cast(float, u0 & 0xffff0000u), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+  const f32x2 r = x - hf;                                                                   // exact
+  const uint32_t r0 = __builtin_bit_cast(uint32_t, r[0]), r1 = __builtin_bit_cast(uint32_t, r[1]);
+  m = __builtin_amdgcn_perm(r1, r0, HI);
+  const f32x2 mf = {__builtin_bit_cast(float, r0 & 0xffff0000u), __builtin_bit_cast(float, r1 & 0xffff0000u)};
+  const f32x2 q = r - mf;                                                                   // exact, <= 8 bits
+  l = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q[1]), __builtin_bit_cast(uint32_t, q[0]), HI);
 }
 // element pair e (bf16 elements 2e, 2e + 1) of the three plane vectors of a fragment
 __device__ __forceinline__ void split3v(float x0, float x1, u32x4 (&pl)[3], int e) {

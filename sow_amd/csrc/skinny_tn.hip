@@ -752,6 +752,178 @@ template <bool X3> __global__ __launch_bounds__(256, 2) void tn_partial_dma_f32_
   }
 }
 
+// =================================================================================================
+// fp32 wide variant (3 x bf16 products): TWO 64-column groups of M per workgroup, as the bf16 wide kernel -- with the
+// matrix pipe out of the way (3 x bf16) the narrow fp32 kernel is bound by the DMA path as a whole, and half of what it
+// moves is the S stream (h / dh rows from L2, once per column group).  6 waves, wave-private rings of 4 stages of
+// [8 tok] x ([128] M + [64] S) fp32 = 6 KiB (6 DMA instructions of 4 rows x 256 B), 144 KiB of LDS, one workgroup per CU.
+// A k-step is 16 tokens = two consecutive stages of the wave (lane-half lh takes stage 2 q + lh).  Lane li owns columns
+// (2 li, 2 li + 1) of every 64-column image, so accumulator (g, a, c) register `reg` is G_g[2 * acc_row + a][2 * li + c],
+// the layout of the narrow kernel; the column groups are processed one after the other to keep the registers under 256.
+// =================================================================================================
+constexpr int TNFW_DEPTH = 4;
+constexpr int TNFW_STAGE_BYTES = 6144;
+constexpr int TNFW_WAVES = 6;
+
+__global__ __launch_bounds__(64 * TNFW_WAVES, 1) void tn_partial_dma_f32_wide_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  int b = blockIdx.x, jid = 0;
+  const int ncg2_0 = (p.job[0].ncg + 1) / 2;
+  if (p.njobs > 1 && b >= ncg2_0 * p.ns) {
+    b -= ncg2_0 * p.ns;
+    jid = 1;
+  }
+  const float* Mg = (const float*)(jid ? p.job[1].M : p.job[0].M);
+  const float* Sg = (const float*)(jid ? p.job[1].S : p.job[0].S);
+  float* Pg = jid ? p.job[1].partial : p.job[0].partial;
+  const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
+  const int D = jid ? p.job[1].D : p.job[0].D;
+  const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
+  const int dcg = b / p.ns, slab = b % p.ns;
+  const int d0 = dcg * 2 * TN_BD;
+  const int64_t t_begin = (int64_t)slab * p.slab_len;
+  int64_t t_end = t_begin + p.slab_len;
+  if (t_end > p.T) t_end = p.T;
+  char* ring = smem + w * (TNFW_DEPTH * TNFW_STAGE_BYTES);
+  const int ngroups = t_begin < t_end ? (int)((t_end - t_begin + 7) / 8) : 0;
+  const int nw = ngroups > w ? (ngroups - w + TNFW_WAVES - 1) / TNFW_WAVES : 0;   // 8-token groups of this wave
+
+  // DMA instruction q = 2 * tile + half: tile 0, 1 = the two M column groups, 2 = S; half = token rows 4 half .. 4 half + 3
+  const int drow = lane >> 4, dpc = lane & 15;
+  const char* zp = zero_page_for(lane);
+  const char* ptr[6];
+  int64_t step[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int tile = q >> 1, half = q & 1;
+    const int64_t tt = t_begin + (int64_t)w * 8 + half * 4 + drow;
+    if (tile < 2) {
+      const bool ok = d0 + tile * TN_BD + dpc * 4 < D;
+      ptr[q] = ok ? (const char*)(Mg + tt * ldm + d0 + tile * TN_BD + dpc * 4) : zp;
+      step[q] = ok ? (int64_t)TNFW_WAVES * 8 * ldm * 4 : 0;
+    } else {
+      ptr[q] = (const char*)(Sg + tt * 64 + dpc * 4);
+      step[q] = (int64_t)TNFW_WAVES * 8 * 64 * 4;
+    }
+  }
+  auto issue = [&](int i) {   // strictly in order: ptr[] points at group i
+    const int64_t tt0 = t_begin + (int64_t)(w + TNFW_WAVES * i) * 8;
+    char* slot = ring + (i % TNFW_DEPTH) * TNFW_STAGE_BYTES;
+    const bool whole = tt0 + 8 <= t_end;   // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const void* src = ptr[q];
+      if (!whole && tt0 + (q & 1) * 4 + drow >= t_end) src = zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
+      ptr[q] += step[q];
+    }
+  };
+
+  f32x16 acc[2][2][2];   // [column group][row parity a][S column parity c]
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][a][c][i] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const uint32_t ring_addr = lds_addr(ring);
+  const int pre = nw < TNFW_DEPTH ? nw : TNFW_DEPTH;
+  for (int i = 0; i < pre; ++i) issue(i);
+  const int npair = (nw + 1) / 2;
+  for (int q = 0; q < npair; ++q) {
+    const bool has1 = 2 * q + 1 < nw;
+    const int last = has1 ? 2 * q + 1 : 2 * q;
+    const int issued = nw < 2 * q + TNFW_DEPTH ? nw : 2 * q + TNFW_DEPTH;
+    tnw_wait_stages(issued - 1 - last);   // 6 DMA instructions per stage, at most two stages newer
+    __builtin_amdgcn_sched_barrier(0);
+    const int st = 2 * q + (has1 ? lh : 0);
+    const uint32_t ad = ring_addr + (uint32_t)((st % TNFW_DEPTH) * TNFW_STAGE_BYTES) + (uint32_t)(li * 8);
+    const bool dead = !has1 && lh == 1;
+    f32x2 sv[8];
+    DS_READ_B64(sv[0], ad, 4096 + 0 * 256);
+    DS_READ_B64(sv[1], ad, 4096 + 1 * 256);
+    DS_READ_B64(sv[2], ad, 4096 + 2 * 256);
+    DS_READ_B64(sv[3], ad, 4096 + 3 * 256);
+    DS_READ_B64(sv[4], ad, 4096 + 4 * 256);
+    DS_READ_B64(sv[5], ad, 4096 + 5 * 256);
+    DS_READ_B64(sv[6], ad, 4096 + 6 * 256);
+    DS_READ_B64(sv[7], ad, 4096 + 7 * 256);
+    f32x2 mv[8];
+    DS_READ_B64(mv[0], ad, 0 * 256);
+    DS_READ_B64(mv[1], ad, 1 * 256);
+    DS_READ_B64(mv[2], ad, 2 * 256);
+    DS_READ_B64(mv[3], ad, 3 * 256);
+    DS_READ_B64(mv[4], ad, 4 * 256);
+    DS_READ_B64(mv[5], ad, 5 * 256);
+    DS_READ_B64(mv[6], ad, 6 * 256);
+    DS_READ_B64(mv[7], ad, 7 * 256);
+    LGKM_WAIT0();
+    u32x4 sp[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) split3v(dead ? 0.f : sv[2 * pr][c], dead ? 0.f : sv[2 * pr + 1][c], sp[c], pr);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      u32x4 mp[2][3];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) split3v(dead ? 0.f : mv[2 * pr][a], dead ? 0.f : mv[2 * pr + 1][a], mp[a], pr);
+      if (g == 0) {   // fetch the second column group while the first multiplies
+        DS_READ_B64(mv[0], ad, 2048 + 0 * 256);
+        DS_READ_B64(mv[1], ad, 2048 + 1 * 256);
+        DS_READ_B64(mv[2], ad, 2048 + 2 * 256);
+        DS_READ_B64(mv[3], ad, 2048 + 3 * 256);
+        DS_READ_B64(mv[4], ad, 2048 + 4 * 256);
+        DS_READ_B64(mv[5], ad, 2048 + 5 * 256);
+        DS_READ_B64(mv[6], ad, 2048 + 6 * 256);
+        DS_READ_B64(mv[7], ad, 2048 + 7 * 256);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[g][a][c] = mfma_x3(mp[a], sp[c], acc[g][a][c]);
+      if (g == 0) LGKM_WAIT0();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (2 * q + TNFW_DEPTH < nw) issue(2 * q + TNFW_DEPTH);
+    if (2 * q + 1 + TNFW_DEPTH < nw) issue(2 * q + 1 + TNFW_DEPTH);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // cross-wave sum of the six [64][64] fp32 partials of each column group through LDS (aliases the rings)
+  float* red = (float*)smem;  // [6 waves][64][64]
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    if (2 * dcg + g >= ncg) break;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          red[w * 4096 + (2 * acc_row(reg, lane) + a) * 64 + 2 * li + c] = acc[g][a][c][reg];
+    __syncthreads();
+    float* P = Pg + ((int64_t)slab * ncg * TN_BD + d0 + g * TN_BD) * 64;
+    for (int v = t; v < 1024; v += 64 * TNFW_WAVES) {   // 1024 float4 of the [64][64] tile
+      f32x4 s0 = *(const f32x4*)(red + v * 4);
+#pragma unroll
+      for (int k = 1; k < TNFW_WAVES; ++k) s0 += *(const f32x4*)(red + k * 4096 + v * 4);
+      *(f32x4*)(P + v * 4) = s0;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Deterministic slab reduction + crop + optional transpose + cast.
 //   out[d][r]   (transpose = 0, ld = out_ld)   or   out[r][d]   (transpose = 1)
@@ -847,12 +1019,12 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
   int ns;
   int64_t max_ns = (T + 511) / 512;
   if (max_ns < 1) max_ns = 1;
-  if (dtype == SOW_F32) {
+  if (dtype == SOW_F32 && (sw_on(SW_F32_EXACT) || sw_on(SW_TN_NARROW))) {
     ns = 512 / total_colgroups;
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
     if (ns > 8 && (ns & ~7) * 10 >= ns * 9) ns &= ~7;
-  } else {
+  } else {   // bf16, and fp32 on the wide 3 x bf16 kernel
     // the wide kernel owns two column groups per block and one 8-wave workgroup per CU: the largest multiple of 8
     // that keeps the grid within ONE round of 256 (measured at d = 768, 12 double groups: 16 slabs / 192 blocks
     // 22.2 us, 21 / 252 26.9 us, 24 / 288 30.5 us; llama_60m: 32 slabs for 512/512, 16 for the 1376-wide layers)
@@ -936,7 +1108,13 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
       dma = dma && J.D % 4 == 0 && J.ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
     }
-    if (dma) {
+    if (dma && !sw_on(SW_F32_EXACT) && !sw_on(SW_TN_NARROW)) {
+      constexpr int LDSW = TNFW_WAVES * TNFW_DEPTH * TNFW_STAGE_BYTES;  // 144 KiB
+      int blocks2 = 0;   // two 64-column groups per block
+      for (int j = 0; j < p.njobs; ++j) blocks2 += (p.job[j].ncg + 1) / 2 * p.ns;
+      SOW_SET_MAX_LDS_ONCE(LDSW, tn_partial_dma_f32_wide_kernel);
+      hipLaunchKernelGGL(tn_partial_dma_f32_wide_kernel, dim3(blocks2), dim3(64 * TNFW_WAVES), LDSW, stream, p);
+    } else if (dma) {
       constexpr int LDS = 4 * TNF_DEPTH * TNF_STAGE_BYTES;  // 64 KiB
       if (sw_on(SW_F32_EXACT)) {
         SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_f32_kernel<false>);

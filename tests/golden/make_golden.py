@@ -737,10 +737,59 @@ def case_tt_newton():
     npz("tt_newton", **arrs)
 
 
+
+
+# ----------------------------------------------------------------------------
+# round 2 -- a14: simple_train.py:596-650 with gradient accumulation 3 (the predicate of :618-626 fires on two micro-steps
+# of every accumulation update and never on its last one)
+# ----------------------------------------------------------------------------
+def case_train_trace_ga():
+    from transformers import AutoModelForCausalLM, LlamaConfig
+    sys.path.insert(0, os.path.dirname(HERE))
+    import protocols as P
+
+    be = _protocol_backend()
+    be.accumulate = accumulate
+    torch.manual_seed(42)
+    model = AutoModelForCausalLM.from_config(LlamaConfig(**P.LLAMA_TINY))
+    rank = 6
+    model = prepare_sow(model, SoWConfig(target_modules=P.LLAMA_TARGETS, rank=rank, init_method="normal", scale=1.0,
+                                         decompose=None, device="cpu"))
+    for m in model.modules():
+        if isinstance(m, SoWLinear):
+            m.init_method = "normal_QR"
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(P.llama_param_groups(model, be))
+    ga, sow_acc, micro = 3, 1, 15
+    tokens = torch.randint(0, 256, (micro, 4, 16), generator=torch.Generator().manual_seed(44))
+    rec = DrawRecorder()
+    draws = []
+
+    def on_acc(n, mdl):
+        draws.append(list(rec.draws))
+        rec.draws.clear()
+
+    rec.__enter__()
+    losses, fired = P.pretrain_protocol(model, opt, be, tokens, ga, sow_acc, on_accumulate=on_acc)
+    rec.__exit__()
+    arrs = {f"init::{k}": v for k, v in init_state.items() if v.numel() > 0}
+    arrs.update(tokens=tokens, losses=np.array(losses, dtype=np.float64), fired=np.array(fired), ga=ga, sow_accumulation=sow_acc,
+                rank=rank)
+    for ai, dl in enumerate(draws):
+        for li, d in enumerate(dl):
+            arrs[f"draw::{ai}::{li}"] = d
+    final = model.state_dict()
+    probe = "model.layers.1.mlp.down_proj"
+    arrs["final::acc_down"] = final[probe + ".acc_downweight"]
+    arrs["final::A"] = final[probe + ".downscale_weights.0"]
+    arrs["final::B"] = final[probe + ".upscale_weights.0"]
+    npz("train_trace_ga3", **arrs)
+    print("ga3 losses", losses, "accumulate fired at global steps", fired)
+
 CASES = dict(forward_backward=case_forward_backward, accumulate=case_accumulate, qr_svd=case_qr_svd, prepare=case_prepare,
              reset_optimizer=case_reset_optimizer, tt=case_tt, tt_optim=case_tt_optim, train_trace=case_train_trace,
              protocol_traces=case_protocol_traces, checkpoint_layer=case_checkpoint_layer, load_sow=case_load_sow,
-             tt_newton=case_tt_newton)
+             tt_newton=case_tt_newton, train_trace_ga=case_train_trace_ga)
 
 if __name__ == "__main__":
     torch.set_num_threads(4)

@@ -87,5 +87,11 @@ def reset_optimizer(optimizer, group_id):
             st.update(O.reset_optimizer_state(st, group.get("amsgrad", False)))
 
 
+def accumulate(model):
+    for _, m in model.named_modules():
+        if isinstance(m, OracleSoWLinear):
+            m.accumulate()
+
+
 BACKEND = types.SimpleNamespace(SoWLinear=OracleSoWLinear, SoWConfig=OracleConfig, prepare_sow=prepare_sow,
-                                reset_optimizer=reset_optimizer)
+                                reset_optimizer=reset_optimizer, accumulate=accumulate)

@@ -235,3 +235,93 @@ def replay_and_check(be, g, proto, device, set_draw, tol):
     bad = {k: v for k, v in errs.items() if not v[0] <= v[1]}
     assert not bad, bad
     return errs
+
+
+# ---------------------------------------------------------------------------------------------
+# scripts/simple_train.py:596-650 with gradient accumulation > 1 (the predicate of :618-626)
+# ---------------------------------------------------------------------------------------------
+LLAMA_TINY = dict(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                  vocab_size=256, max_position_embeddings=64, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                  attn_implementation="eager")
+LLAMA_TARGETS = ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"]
+
+
+def pretrain_protocol(model, opt, backend, tokens, ga, sow_accumulation, offset=0, reinit=None, on_accumulate=None):
+    """simple_train.py:596-650, line for line where it touches the SoW path: loss / ga, backward, the accumulate predicate
+    `(global_step % ga or ga == 1) and update_step > offset and (update_step - offset) % (ga * sow_accumulation) == 0`
+    (quirk kept: with ga > 2 it is true on SEVERAL micro-steps of the same update, and never on the update's last one),
+    accumulate(model) + reset_optimizer(group 1) between backward and the optimizer step, `continue` on non-boundary
+    micro-steps.  Returns (losses per micro-step, list of global_steps at which accumulate fired)."""
+    global_step = update_step = 0
+    losses, fired = [], []
+    accumulation_step = int(ga * sow_accumulation)
+    for k in range(tokens.shape[0]):
+        global_step += 1
+        batch = tokens[k]
+        loss = model(input_ids=batch, labels=batch.clone()).loss
+        losses.append(float(loss.detach()))
+        (loss / ga).backward()
+        if (global_step % ga or ga == 1) and update_step > offset and (update_step - offset) % accumulation_step == 0:
+            if reinit is not None:
+                for i, (_, m) in enumerate(sow_layers(model, backend)):
+                    reinit(len(fired), i, m)
+            backend.accumulate(model)
+            backend.reset_optimizer(opt, group_id=1)
+            fired.append(global_step)
+            if on_accumulate is not None:
+                on_accumulate(len(fired) - 1, model)
+        if global_step % ga != 0:
+            continue
+        opt.step()
+        opt.zero_grad()
+        update_step += 1
+    return losses, fired
+
+
+def llama_param_groups(model, backend):
+    """Two AdamW groups as simple_train.py:389-405, 502-506: everything else, then the factors (group 1)."""
+    special, ids = [], set()
+    for _, m in sow_layers(model, backend):
+        for w in list(m.downscale_weights) + list(m.upscale_weights):
+            special.append(w)
+            ids.add(id(w))
+    others = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
+    return [{"params": others, "lr": 1e-3, "weight_decay": 0.0, "eps": 1e-4},
+            {"params": special, "lr": 5e-3, "weight_decay": 0.0, "eps": 1e-4}]
+
+
+def replay_pretrain_ga(be, g, device, set_draw, tol):
+    """Run pretrain_protocol on backend `be` with the inputs of tests/golden/train_trace_ga3.npz and compare the loss
+    trace, the micro-steps at which accumulate fired (exact) and the final accumulator / factors of one layer."""
+    import transformers
+    torch.manual_seed(42)
+    model = transformers.AutoModelForCausalLM.from_config(transformers.LlamaConfig(**LLAMA_TINY))
+    model = be.prepare_sow(model, be.SoWConfig(target_modules=LLAMA_TARGETS, rank=int(g["rank"]), init_method="normal", scale=1.0,
+                                               decompose=None, device="cpu"))
+    sd = {k[len("init::"):]: v for k, v in g.items() if k.startswith("init::")}
+    missing = model.load_state_dict(sd, strict=False)
+    assert all(k.endswith("acc_upweight") or k.endswith("acc_downweight") for k in missing.missing_keys)
+    model.to(device)
+    layers = sow_layers(model, be)
+    for _, m in layers:
+        m.init_method = "normal_QR"
+    opt = torch.optim.AdamW(llama_param_groups(model, be))
+    tokens = g["tokens"].to(device)
+
+    def reinit(n, li, m):
+        set_draw(m, g[f"draw::{n}::{li}"])
+
+    losses, fired = pretrain_protocol(model, opt, be, tokens, int(g["ga"]), int(g["sow_accumulation"]), reinit=reinit)
+    assert fired == [int(v) for v in g["fired"]], (fired, g["fired"])
+    for got, want in zip(losses, g["losses"].tolist()):
+        assert abs(got - want) <= tol["loss"] * abs(want), (losses, g["losses"].tolist())
+    probe = dict(model.named_modules())["model.layers.1.mlp.down_proj"]
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.double()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    assert rel(probe.acc_downweight.data, g["final::acc_down"]) < tol["acc"]
+    assert rel(probe.downscale_weights[0].data, g["final::A"]) < tol["acc"]
+    assert rel(probe.upscale_weights[0].data, g["final::B"]) < tol["final"]
+    return losses, fired

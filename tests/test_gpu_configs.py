@@ -489,3 +489,38 @@ def test_accumulate_llama60m_unhooked_draws_are_orthonormal_and_fast():
     assert different > 1e-3          # independent draws per layer
     print(f"accumulate(llama_60m, 56 layers): {ms:.2f} ms")
     assert ms < 10.0
+
+
+def test_pretrain_protocol_gradient_accumulation_3():
+    """a14 with gradient accumulation: simple_train.py:596-650, GA = 3, on the HIP path through prepare_sow / accumulate(model)
+    (batched) / reset_optimizer -- the predicate fires on micro-steps 10 and 11 exactly as in the reference's run."""
+    import sow_amd
+    be = types.SimpleNamespace(SoWLinear=sow_amd.SoWLinear, SoWConfig=sow_amd.SoWConfig, prepare_sow=sow_amd.prepare_sow,
+                               reset_optimizer=sow_amd.reset_optimizer, accumulate=sow_amd.accumulate)
+    g = load_golden("train_trace_ga3")
+    losses, fired = P.replay_pretrain_ga(be, g, DEV, _set_draw, dict(loss=2e-4, acc=1e-3, final=1e-3))
+    assert fired == [10, 11]
+
+
+@pytest.mark.parametrize("shape", [(8200, 768, 768, 50), (4100, 512, 1376, 50), (2050, 264, 72, 34)])
+def test_fp32_3xbf16_agrees_with_exact_fp32_mfma(shape):
+    """fp32 tensors: the default 3 x bf16 form (products on the bf16 matrix pipe, dropped cross terms <= 2^-23 per product)
+    against the exact v_mfma_f32_32x32x2_f32 form of the same kernels (F32_EXACT switch) and against the oracle."""
+    from sow_amd import _lib, ops
+    T, di, do, r = shape
+    gen = torch.Generator().manual_seed(17)
+    x, dy = torch.randn(T, di, generator=gen), torch.randn(T, do, generator=gen)
+    A = torch.linalg.qr(torch.randn(di, r, generator=gen))[0].contiguous()
+    B = torch.randn(r, do, generator=gen) * 0.05
+    g = lambda t: t.to(DEV)
+    y, h = ops.sow_forward(g(x), g(A), g(B), None, None, None, 0.5)
+    dx, dA, dB, _ = ops.sow_backward(g(dy), g(x), h, g(A), g(B), None, None, 0.5, False)
+    with _lib.switch(F32_EXACT=1):
+        y0, h0 = ops.sow_forward(g(x), g(A), g(B), None, None, None, 0.5)
+        dx0, dA0, dB0, _ = ops.sow_backward(g(dy), g(x), h0, g(A), g(B), None, None, 0.5, False)
+    for a, b in ((y, y0), (dx, dx0), (dA, dA0), (dB, dB0)):
+        assert rel_err(a.cpu(), b.cpu()) < 2e-6
+    y_ref = O.sow_forward(x, [A], [B], None, None, 0.5, None)
+    dx_ref, dA_ref, dB_ref, _ = O.sow_backward(dy, x, [A], [B], None, None, 0.5, False)
+    assert rel_err(y.cpu(), y_ref) < TOL and rel_err(dx.cpu(), dx_ref) < TOL
+    assert rel_err(dA.cpu(), dA_ref[0]) < TOL and rel_err(dB.cpu(), dB_ref[0]) < TOL

@@ -264,3 +264,18 @@ def test_tt_newton_and_reciprocal():
     rec = O.tt_reciprocal([g[f"recip_in{i}"] for i in range(3)])
     for i in range(3):
         assert rel_err(rec[i], g[f"recip_out{i}"]) < 1e-5
+
+
+def test_pretrain_protocol_gradient_accumulation_3_oracle():
+    """a14: simple_train.py:596-650 with gradient_accumulation = 3 on a tiny Llama -- the accumulate predicate (:618-626) fires on
+    micro-steps 10 and 11 (two micro-steps of the same update, never its last one); loss trace and final state vs the reference."""
+    pytest.importorskip("transformers")
+    import oracle_backend
+    import protocols as P
+    g = load_golden("train_trace_ga3")
+
+    def set_draw(m, draw):
+        m.next_draws = [draw]
+
+    losses, fired = P.replay_pretrain_ga(oracle_backend.BACKEND, g, "cpu", set_draw, dict(loss=2e-6, acc=1e-4, final=1e-4))
+    assert fired == [10, 11] and len(losses) == 15
