@@ -533,13 +533,17 @@ int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream) {
     const int nsplit = p.st_per > 0 ? ceil_div((p.D1 + 63) / 64, p.st_per) : ceil_div((p.D2 + 63) / 64, p.sl_per);
     grid = p.ntb * nsplit;
   }
-  // commas of the template-id would split the macro argument: name the instantiations first
-  using KernelFn = void (*)(const ChainParams);
   const bool x3 = !sw_on(SW_F32_EXACT);
-  const KernelFn k = bwd ? (x3 ? (KernelFn)chain2f_kernel<true, true> : (KernelFn)chain2f_kernel<true, false>)
-                         : (x3 ? (KernelFn)chain2f_kernel<false, true> : (KernelFn)chain2f_kernel<false, false>);
-  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);
+#define C3_LAUNCH(...)                                                                  \
+  do {                                                                                  \
+    SOW_SET_MAX_LDS_ONCE(C3_LDS, __VA_ARGS__);                                          \
+    hipLaunchKernelGGL(__VA_ARGS__, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);   \
+  } while (0)
+  if (bwd && x3) C3_LAUNCH(chain2f_kernel<true, true>);
+  else if (bwd) C3_LAUNCH(chain2f_kernel<true, false>);
+  else if (x3) C3_LAUNCH(chain2f_kernel<false, true>);
+  else C3_LAUNCH(chain2f_kernel<false, false>);
+#undef C3_LAUNCH
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }

@@ -67,19 +67,27 @@ __device__ __forceinline__ u32x4 join2(u32x2 lo, u32x2 hi) { return (u32x4){lo[0
 // matrix-pipe time per product, and -- unlike the fp32 MFMA, which blocks every other instruction of its SIMD while
 // it runs (tools/probe4.hip) -- the bf16 MFMA lets LDS reads, VALU and DMA issue of the partner wave pass.
 // The price is the split: 11 VALU instructions per pair of operand elements.
+// two fp32 subtractions in one instruction, on a 64-bit register pair.  Integer-typed on purpose: hipcc (ROCm 7.2) folds
+// element 1 of a float vector into element 0 when the element is bit-cast (seen in the ISA of an f32x2 version of split3:
+// both halves of the mid plane came from element 0 -- the lo-plane accuracy was silently lost, caught by the 2e-6 loss bar of
+// the config-4 protocol trace).
+__device__ __forceinline__ uint64_t pk_sub_f32(uint64_t a, uint64_t b) {
+  uint64_t r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
   // 9 VALU instructions per pair: 2 masks + 1 packed subtract per level, one v_perm_b32 per plane to pack the high halves
   constexpr uint32_t HI = 0x07060302u;   // v_perm_b32(b, a, HI) = (a >> 16) | (b & 0xffff0000)
+  constexpr uint32_t MK = 0xffff0000u;
   const uint32_t u0 = __builtin_bit_cast(uint32_t, x0), u1 = __builtin_bit_cast(uint32_t, x1);
   h = __builtin_amdgcn_perm(u1, u0, HI);
-  const f32x2 x = {x0, x1};
-  const f32x2 hf = {__builtin_bit_cast(float, u0 & 0xffff0000u), __builtin_bit_cast(float, u1 & 0xffff0000u)};
-  const f32x2 r = x - hf;                                                                   // exact
-  const uint32_t r0 = __builtin_bit_cast(uint32_t, r[0]), r1 = __builtin_bit_cast(uint32_t, r[1]);
+  const uint64_t x64 = (uint64_t)u0 | ((uint64_t)u1 << 32);
+  const uint64_t r64 = pk_sub_f32(x64, (uint64_t)(u0 & MK) | ((uint64_t)(u1 & MK) << 32));          // exact residuals
+  const uint32_t r0 = (uint32_t)r64, r1 = (uint32_t)(r64 >> 32);
   m = __builtin_amdgcn_perm(r1, r0, HI);
-  const f32x2 mf = {__builtin_bit_cast(float, r0 & 0xffff0000u), __builtin_bit_cast(float, r1 & 0xffff0000u)};
-  const f32x2 q = r - mf;                                                                   // exact, <= 8 bits
-  l = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q[1]), __builtin_bit_cast(uint32_t, q[0]), HI);
+  const uint64_t q64 = pk_sub_f32(r64, (uint64_t)(r0 & MK) | ((uint64_t)(r1 & MK) << 32));           // exact, <= 8 bits
+  l = __builtin_amdgcn_perm((uint32_t)(q64 >> 32), (uint32_t)q64, HI);
 }
 // element pair e (bf16 elements 2e, 2e + 1) of the three plane vectors of a fragment
 __device__ __forceinline__ void split3v(float x0, float x1, u32x4 (&pl)[3], int e) {

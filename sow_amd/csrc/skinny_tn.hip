@@ -1031,6 +1031,9 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
     const int cg2 = total_colgroup_pairs > 0 ? total_colgroup_pairs : 1;
     ns = (256 / cg2) & ~7;
     if (ns < 8) ns = 256 / cg2;
+    // fp32 wide kernel: latency-bound on the bytes one CU keeps in flight (144 KiB of rings), so every CU counts:
+    // no rounding to a multiple of 8 (d = 768: 21 slabs / 252 blocks instead of 16 / 192)
+    if (dtype == SOW_F32) ns = 256 / cg2;
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
   }
