@@ -537,7 +537,7 @@ int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream) {
 #define C3_LAUNCH(...)                                                                  \
   do {                                                                                  \
     SOW_SET_MAX_LDS_ONCE(C3_LDS, __VA_ARGS__);                                          \
-    hipLaunchKernelGGL(__VA_ARGS__, dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p);   \
+    hipLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(C3_THREADS), C3_LDS, stream, p); \
   } while (0)
   if (bwd && x3) C3_LAUNCH(chain2f_kernel<true, true>);
   else if (bwd) C3_LAUNCH(chain2f_kernel<true, false>);
