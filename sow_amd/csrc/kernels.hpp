@@ -29,6 +29,7 @@ struct ChainParams {
   const void* Hload;
   int nt_store;   // chain2: write Y with the non-temporal hint
   int nt_load;    // chain2 (experiment): stream X with the non-temporal hint
+  int pair_flush; // chain2: store two output slices at a time (256-byte pieces per row)
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
