@@ -9,6 +9,7 @@ from .tt import TensorTrain  # noqa: F401
 from .optimizer import TTAdam, TTSGD, FactorAdamW  # noqa: F401
 from .tensor_linear import TensorTrainLinear  # noqa: F401
 from .dp import FactorBucket, factor_parameters  # noqa: F401
+from .group import group_siblings, ungroup_siblings  # noqa: F401
 from .utils import qr_weight, svd_weight, pad_matrix, unpad_matrix, closest_factorization  # noqa: F401
 
 __version__ = "0.1.0"

@@ -259,6 +259,9 @@ int launch_gemm(const void* A, int64_t lda, bool transA, const void* B, int64_t 
   if (dtype == SOW_BF16) {
     SOW_GEMM_DISPATCH(bf16_t)
   } else if (dtype == SOW_F32) {
+    // vector-aligned fp32 products run on the bf16 matrix pipe as 3 x bf16 splits (gemm_x3.hip; F32_EXACT switch: fp32 MFMA)
+    if (p.vecA && p.vecB && p.vecC && K >= 16 && !sw_on(SW_F32_EXACT))
+      return launch_gemm_x3(A, lda, transA, B, ldb, transB, C, ldc, bias, M, N, K, alpha, beta, stream);
     SOW_GEMM_DISPATCH(float)
   }
 #undef SOW_GEMM_DISPATCH

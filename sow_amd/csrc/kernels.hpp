@@ -102,6 +102,9 @@ int launch_tn_reduce_batch(const ReduceParams* descs, const int* starts, int n, 
 // gemm.hip
 int launch_gemm(const void* A, int64_t lda, bool transA, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
                 const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream);
+// gemm_x3.hip: the same contract for fp32 tensors on the bf16 matrix pipe (3 x bf16 splits); vector-aligned operands only
+int launch_gemm_x3(const void* A, int64_t lda, bool transA, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
+                   const void* bias, int64_t M, int N, int K, float alpha, float beta, hipStream_t stream);
 // gemm2.hip (bf16 streaming GEMM with K-extension: the dense-accumulator form of the layer)
 bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                      const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,

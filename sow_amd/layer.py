@@ -135,6 +135,11 @@ class SoWLinear(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """sow.py:107-126 in one fused call: accumulator term (not scaled) + scale * (x A) B + bias."""
+        group = self.__dict__.get("_sibling_group")     # sow_amd.group.group_siblings: q/k/v or gate/up in one launch
+        if group is not None:
+            y = group.forward(self, x)
+            if y is not None:
+                return y
         A, B = self._cat_factors()
         return _SoWFunction.apply(x, A, B, self.acc_downweight, self.acc_upweight, self.bias, float(self.scale),
                                   getattr(self, "_grad_sink", None))

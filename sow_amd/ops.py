@@ -187,7 +187,7 @@ class LayerCall:
     own workspace (workspace_bytes())."""
 
     def __init__(self, x2, A, B, *, acc_down=None, acc_up=None, bias=None, scale=1.0, y=None, h=None, dy2=None, dx=None,
-                 out=None, grad_beta=0.0, workspace=None):
+                 out=None, grad_beta=0.0, workspace=None, forward_only=False):
         dev = _need_gpu(x2, A, B, bias, y, h, dy2, dx, workspace)
         self.dtype = _dt(x2)
         T, d_in = x2.shape
@@ -202,9 +202,12 @@ class LayerCall:
         self.y = y if y is not None else torch.empty((T, d_out), dtype=x2.dtype, device=dev)
         self.h = h if h is not None else torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)
         self.dx = dx
-        nws = workspace_bytes(T, d_in, d_out, r, acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0, kind, x2.dtype)
-        self.workspace = workspace if workspace is not None else _ws(nws, dev)
-        if self.workspace.numel() < nws:
+        r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
+        # a forward-only call needs scratch for a few shapes only (sow_forward_workspace_bytes), often none at all
+        nws = (_forward_workspace_bytes(_lib.load(), T, d_in, d_out, r, r_acc, kind, self.dtype) if forward_only
+               else workspace_bytes(T, d_in, d_out, r, r_acc, kind, x2.dtype))
+        self.workspace = workspace if workspace is not None else (_ws(nws, dev) if nws else None)
+        if self.workspace is not None and self.workspace.numel() < nws:
             raise ValueError("sow_amd.LayerCall: workspace too small")
         dA, dB, dbias = out if out is not None else (None, None, None)
         self._keep = (x2, A, B, acc_down, acc_up, bias, dy2, dA, dB, dbias)     # the struct holds raw pointers
@@ -213,7 +216,8 @@ class LayerCall:
             acc_up=_ptr(acc_up) if kind == _lib.ACC_LOWRANK else None, bias=_ptr(bias), y=_ptr(self.y), h_save=_ptr(self.h),
             dy=_ptr(dy2), dx=_ptr(dx), dA=_ptr(dA), dB=_ptr(dB), dbias=_ptr(dbias), T=T, d_in=d_in, d_out=d_out, r_live=r,
             r_acc=acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0, acc_kind=kind, scale=float(scale),
-            grad_beta=float(grad_beta), workspace=_ptr(self.workspace), workspace_bytes=self.workspace.numel())
+            grad_beta=float(grad_beta), workspace=_ptr(self.workspace),
+            workspace_bytes=0 if self.workspace is None else self.workspace.numel())
 
 
 class LayerGroup:

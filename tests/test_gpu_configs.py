@@ -524,3 +524,73 @@ def test_fp32_3xbf16_agrees_with_exact_fp32_mfma(shape):
     dx_ref, dA_ref, dB_ref, _ = O.sow_backward(dy, x, [A], [B], None, None, 0.5, False)
     assert rel_err(y.cpu(), y_ref) < TOL and rel_err(dx.cpu(), dx_ref) < TOL
     assert rel_err(dA.cpu(), dA_ref[0]) < TOL and rel_err(dB.cpu(), dB_ref[0]) < TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# sibling grouping at the module level (sow_amd.group_siblings)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_group_siblings_in_a_llama_block(dtype):
+    """q/k/v and gate/up of a tiny Llama run through ONE autograd node per group after group_siblings(model): loss, every
+    parameter gradient and the input-embedding gradient are bit-identical to the ungrouped model (same kernels per layer,
+    dX of the siblings summed in the same order autograd uses), also under gradient checkpointing; a `keep` (dense
+    accumulator) model groups too."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+
+    from sow_amd import SoWConfig, group_siblings, prepare_sow, ungroup_siblings
+    torch.manual_seed(7)
+    cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=344, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=4, vocab_size=256, max_position_embeddings=128, rms_norm_eps=1e-6,
+                                   tie_word_embeddings=False, attn_implementation="eager")
+    for decompose in (None, "keep"):
+        base = transformers.AutoModelForCausalLM.from_config(cfg)
+        base = prepare_sow(base, SoWConfig(target_modules=["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"],
+                                           rank=8, init_method="normal", scale=0.5, decompose=decompose, device="cpu"))
+        base = base.to(DEV, dtype)
+        twin = copy.deepcopy(base)
+        assert group_siblings(twin) == 4                       # {q,k,v} and {gate,up} in each of the two blocks
+        tokens = torch.randint(0, 256, (8, 96), generator=torch.Generator().manual_seed(1)).to(DEV)   # 768 tokens
+        for ckpt in (False, True):
+            for net in (base, twin):
+                net.zero_grad(set_to_none=True)
+                if ckpt:
+                    net.gradient_checkpointing_enable()
+                    net.train()
+                loss = net(input_ids=tokens, labels=tokens.clone()).loss
+                loss.backward()
+                net._loss = float(loss.detach())
+            assert base._loss == twin._loss, (decompose, ckpt)
+            for (n1, p1), (_, p2) in zip(base.named_parameters(), twin.named_parameters()):
+                if p1.grad is None:
+                    assert p2.grad is None, n1
+                else:
+                    assert torch.equal(p1.grad, p2.grad), (n1, decompose, ckpt)
+        ungroup_siblings(twin)
+        assert not any(hasattr(m, "_sibling_group") for m in twin.modules())
+
+
+def test_group_siblings_falls_back_when_inputs_differ():
+    from sow_amd import SoWLinear, group_siblings
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = SoWLinear(64, 48, bias=True, rank=8, init_method="normal", device=DEV)
+            self.k_proj = SoWLinear(64, 32, bias=False, rank=8, init_method="normal", device=DEV)
+            self.v_proj = SoWLinear(64, 32, bias=False, rank=4, init_method="normal", device=DEV)
+
+    blk = Block()
+    assert group_siblings(blk) == 1
+    x1, x2 = torch.randn(9, 64, device=DEV), torch.randn(9, 64, device=DEV)
+    q = blk.q_proj(x1)               # computes the group on x1, parks k and v
+    k_other = blk.k_proj(x2)         # different input: runs on its own
+    v = blk.v_proj(x1)               # picks up its parked output
+    A, B = blk.k_proj.downscale_weights[0].data.cpu(), blk.k_proj.upscale_weights[0].data.cpu()
+    assert rel_err(k_other.detach().cpu(), O.sow_forward(x2.cpu(), [A], [B], None, None, 1.0, None)) < TOL
+    A, B = blk.v_proj.downscale_weights[0].data.cpu(), blk.v_proj.upscale_weights[0].data.cpu()
+    assert rel_err(v.detach().cpu(), O.sow_forward(x1.cpu(), [A], [B], None, None, 1.0, None)) < TOL
+    A, B = blk.q_proj.downscale_weights[0].data.cpu(), blk.q_proj.upscale_weights[0].data.cpu()
+    assert rel_err(q.detach().cpu(), O.sow_forward(x1.cpu(), [A], [B], None, None, 1.0, blk.q_proj.bias.data.cpu())) < TOL
+    (q.sum() + v.sum() + k_other.sum()).backward()
+    assert blk.k_proj.downscale_weights[0].grad is not None and blk.q_proj.bias.grad is not None
