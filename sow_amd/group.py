@@ -117,8 +117,8 @@ def group_siblings(model: nn.Module, groups: Iterable[Sequence[str]] = DEFAULT_G
     for parent in model.modules():
         for names in groups:
             mods = [getattr(parent, nm, None) for nm in names]
-            if all(isinstance(m, SoWLinear) for m in mods) and len({m.in_features for m in mods}) == 1 \\
-                    and all(m.n_iter == 1 for m in mods):
+            if (all(isinstance(m, SoWLinear) for m in mods) and len({m.in_features for m in mods}) == 1
+                    and all(m.n_iter == 1 for m in mods)):
                 g = SiblingGroup(mods)
                 for m in mods:
                     m._sibling_group = g
