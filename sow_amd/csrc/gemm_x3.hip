@@ -63,24 +63,58 @@ template <bool KC> struct X3Tile {
         *(u32x2*)(dst + GX_PLANE) = u32x2{m0, m1};
         *(u32x2*)(dst + 2 * GX_PLANE) = u32x2{l0, l1};
       } else {
-        // four consecutive rows at one k: element writes (the image is k-contiguous per row)
+        // four consecutive rows (m or n) at one k: the plane images of a k-major operand stay k-major, [32 k][128] bf16 with
+        // 256-byte rows (16-byte chunk c at c ^ ((k & 3) << 2)), and are read transposed (ds_read_b64_tr_b16) as in gemm2.hip
         const int k = idx >> 5, c = idx & 31;
         uint32_t h0, m0, l0, h1, m1, l1;
         split3(v[i][0], v[i][1], h0, m0, l0);
         split3(v[i][2], v[i][3], h1, m1, l1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          char* dst = img + bf16_img_off<GX_BK>(4 * c + e, k >> 3) + (k & 7) * 2;
-          const uint32_t hv = e < 2 ? h0 : h1, mv = e < 2 ? m0 : m1, lv = e < 2 ? l0 : l1;
-          const int sh = (e & 1) * 16;
-          *(uint16_t*)(dst) = (uint16_t)(hv >> sh);
-          *(uint16_t*)(dst + GX_PLANE) = (uint16_t)(mv >> sh);
-          *(uint16_t*)(dst + 2 * GX_PLANE) = (uint16_t)(lv >> sh);
-        }
+        char* dst = img + k * 256 + (((c >> 1) ^ ((k & 3) << 2)) * 16) + (c & 1) * 8;
+        *(u32x2*)(dst) = u32x2{h0, h1};
+        *(u32x2*)(dst + GX_PLANE) = u32x2{m0, m1};
+        *(u32x2*)(dst + 2 * GX_PLANE) = u32x2{l0, l1};
       }
     }
   }
 };
+
+// fragments of the two 32-row tiles at row0, row0 + 32 of an operand, k-step ks, all three planes
+template <bool KC> __device__ __forceinline__ void load_frags(const char* img, int row0, int ks, int lane, u32x4 (&f)[2][3]) {
+  if constexpr (KC) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        f[tl][pl] = *(const u32x4*)(img + pl * GX_PLANE + bf16_img_off<GX_BK>(row0 + tl * 32 + li, 2 * ks + lh));
+  } else {
+    const int g = lane >> 4, jj = lane & 15, q = jj >> 2, pp = jj & 3;
+    const int r1 = 8 * (g >> 1) + q;
+    const uint32_t base = lds_addr(img) + (uint32_t)(ks * 4096 + r1 * 256);
+    u32x2 lo[2][3], hi[2][3];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+      const int col = row0 + tl * 32 + 16 * (g & 1) + 4 * pp;
+      const uint32_t ad = base + (uint32_t)((((col >> 3) ^ ((r1 & 3) << 2)) * 16) + (col & 7) * 2);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        DS_READ_TR(lo[tl][pl], ad + (uint32_t)(pl * GX_PLANE), 0);
+        DS_READ_TR(hi[tl][pl], ad + (uint32_t)(pl * GX_PLANE), 1024);
+      }
+    }
+    // the transposed reads are inline asm: ONE wait for all twelve, with the results as read-write operands so that the
+    // compiler cannot move a use (or a register copy) of a pending result above it
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0][0]), "+v"(hi[0][0]), "+v"(lo[0][1]), "+v"(hi[0][1]), "+v"(lo[0][2]), "+v"(hi[0][2]), "+v"(lo[1][0]),
+                   "+v"(hi[1][0]), "+v"(lo[1][1]), "+v"(hi[1][1]), "+v"(lo[1][2]), "+v"(hi[1][2])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) f[tl][pl] = join2(lo[tl][pl], hi[tl][pl]);
+  }
+}
 
 // TA: A given transposed (stored [K, M]); TB: B given as [N, K].
 template <bool TA, bool TB> __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GemmX3Params p) {
@@ -124,13 +158,8 @@ template <bool TA, bool TB> __global__ __launch_bounds__(256, 2) void gemm_x3_ke
 #pragma unroll
     for (int ks = 0; ks < GX_BK / 16; ++ks) {
       u32x4 af[2][3], bfr[2][3];
-#pragma unroll
-      for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          af[tl][pl] = *(const u32x4*)(As + pl * GX_PLANE + bf16_img_off<GX_BK>(wm * 64 + tl * 32 + li, 2 * ks + lh));
-          bfr[tl][pl] = *(const u32x4*)(Bs + pl * GX_PLANE + bf16_img_off<GX_BK>(wn * 64 + tl * 32 + li, 2 * ks + lh));
-        }
+      load_frags<!TA>(As, wm * 64, ks, lane, af);
+      load_frags<TB>(Bs, wn * 64, ks, lane, bfr);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll

@@ -5,9 +5,10 @@ on the SAME hidden state (the reference swaps each of them for a SoWLinear, prep
 sow.py:107-126 three times).  The layers are independent, so on MI355X they share one grid per kernel (DESIGN.md
 section 4: a launch costs ~8 us of ramp and write drain whatever its size).  `group_siblings(model)` arranges that without
 touching the model code: the first sibling that sees a new input computes the whole group through ONE autograd node and
-parks the other outputs; the other siblings, called with the same tensor, pick theirs up.  Results are bit-identical to
-the ungrouped calls (every layer runs its own workgroups unchanged); a sibling called with a different input, or a
-group that the batched path does not cover, simply runs on its own.
+parks the other outputs; the other siblings, called with the same tensor, pick theirs up.  Every layer runs its own
+workgroups unchanged, so outputs and weight gradients for given inputs are bit-identical to the ungrouped calls; only the
+SUM of the siblings' input gradients may round differently from autograd's own accumulation.  A sibling called with a
+different input, or a group that the batched path does not cover, simply runs on its own.
 """
 from __future__ import annotations
 
@@ -65,9 +66,12 @@ class _SoWGroupFunction(torch.autograd.Function):
                                        bias=bias, scale=ctx.scales[i], h=hs[i], dy2=dy2, dx=torch.empty_like(x2), out=out,
                                        grad_beta=0.0, y=dy2))   # y is not written by backward: any valid buffer
         ops.LayerGroup(calls).backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
-        dx = calls[0].dx
-        for c in calls[1:]:
-            dx = dx + c.dx            # the siblings share x: its gradient is the sum, as autograd forms it for separate layers
+        # the siblings share x: its gradient is the sum of theirs.  Summed last sibling first -- the order in which autograd
+        # accumulates the contributions of separately called layers (nodes run in reverse creation order), so the rounding
+        # matches the ungrouped model as closely as it can
+        dx = calls[-1].dx
+        for c in reversed(calls[:-1]):
+            dx = dx + c.dx
         grads: List[Optional[torch.Tensor]] = []
         for (dA, dB, dbias) in outs:
             grads += [dA, dB, None, None, dbias]

@@ -531,10 +531,10 @@ def test_fp32_3xbf16_agrees_with_exact_fp32_mfma(shape):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_group_siblings_in_a_llama_block(dtype):
-    """q/k/v and gate/up of a tiny Llama run through ONE autograd node per group after group_siblings(model): loss, every
-    parameter gradient and the input-embedding gradient are bit-identical to the ungrouped model (same kernels per layer,
-    dX of the siblings summed in the same order autograd uses), also under gradient checkpointing; a `keep` (dense
-    accumulator) model groups too."""
+    """q/k/v and gate/up of a tiny Llama run through ONE autograd node per group after group_siblings(model): the loss is
+    bit-identical to the ungrouped model (same kernels per layer), every parameter gradient agrees to rounding (the sum of
+    the siblings' input gradients is formed once instead of by autograd's accumulation), also under gradient checkpointing;
+    a `keep` (dense accumulator) model groups too."""
     transformers = pytest.importorskip("transformers")
     import copy
 
@@ -565,7 +565,8 @@ def test_group_siblings_in_a_llama_block(dtype):
                 if p1.grad is None:
                     assert p2.grad is None, n1
                 else:
-                    assert torch.equal(p1.grad, p2.grad), (n1, decompose, ckpt)
+                    assert rel_err(p2.grad.float().cpu(), p1.grad.float().cpu()) < (2e-2 if dtype == torch.bfloat16 else 1e-5), \
+                        (n1, decompose, ckpt)
         ungroup_siblings(twin)
         assert not any(hasattr(m, "_sibling_group") for m in twin.modules())
 
