@@ -72,6 +72,9 @@ def parse():
                     help="--mode train: factor group in a FactorBucket (gradients written straight into one flat buffer, one "
                          "batched reduction, one fused AdamW kernel, ONE all-reduce of the bucket at N > 1 with DDP covering "
                          "the other parameters) instead of torch.optim.AdamW's second param group")
+    ap.add_argument("--no-group-siblings", action="store_true",
+                    help="--mode train: do NOT group q/k/v and gate/up (sow_amd.group_siblings: one autograd node and one grid per "
+                         "kernel for the siblings of a decoder block)")
     ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
                     help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
                          "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
@@ -269,6 +272,10 @@ def train_mode(args, world, rank, device, steps=None, warmup=None, quiet=False):
     model = model.to(device=device, dtype=torch.bfloat16)
     trainable = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
     fused = args.fused_factors
+    grouped = 0
+    if not args.no_group_siblings and not fused:      # (layers attached to a FactorBucket keep their own backward)
+        from sow_amd import group_siblings
+        grouped = group_siblings(model)
     inner = model
     if fused:
         from sow_amd.dp import FactorBucket
@@ -333,7 +340,8 @@ def train_mode(args, world, rank, device, steps=None, warmup=None, quiet=False):
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "llama_60m (HF LlamaForCausalLM from config) + prepare_sow rank 50, batch 128 x seq 256, "
                                f"AdamW 2 groups, accumulate every {args.accumulate_every} steps",
-                   "parallelism": f"ddp{world}", "fused_factors": bool(fused), "final_loss": float(loss.detach())}}
+                   "parallelism": f"ddp{world}", "fused_factors": bool(fused), "sibling_groups": grouped,
+                   "final_loss": float(loss.detach())}}
     if rank == 0 and not quiet:
         print(json.dumps(out))
     del model, inner, opt
@@ -571,7 +579,7 @@ def main():
         try:
             t = train_mode(args, 1, 0, device, steps=max(3, min(args.steps, 10)), warmup=3, quiet=True)
             out["train"] = {"what": t["config"]["workload"], "ms_per_step": t["ms_per_step"], "tokens_per_s": t["value"],
-                            "fused_factors": t["config"]["fused_factors"]}
+                            "fused_factors": t["config"]["fused_factors"], "sibling_groups": t["config"]["sibling_groups"]}
         except Exception as e:  # transformers missing or too old on the box: the headline must still print
             out["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
