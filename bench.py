@@ -154,6 +154,8 @@ class Stack:
             ti = first_of_block.get(gi)        # the block's first group is its last in backward order: then its weights
             if ti is not None and (full or (phases == _lib.BWD_WEIGHTS_PARTIAL and (tn_only is None or ti in tn_only))):
                 tn_ph = _lib.BWD_WEIGHTS_PARTIAL if (self.deferred is not None or not full) else _lib.BWD_WEIGHTS
+                if self.deferred is not None:
+                    tn_ph |= _lib.BWD_GROUP_SLABS      # slab counts planned over the block; reduction descriptors to match
                 if self.side is not None and full:
                     main = torch.cuda.current_stream()
                     self.side.wait_stream(main)          # after this block's data-gradient kernels (they produce dh)
@@ -162,10 +164,7 @@ class Stack:
                 else:
                     self.tn_groups[ti].backward(tn_ph)
                 if self.deferred is not None and full:
-                    for li in reversed(self.tn_layers[ti]):
-                        c = self.calls[li]
-                        self.deferred.add(self.x[li], self.B[li].data, (self.A[li].grad, self.B[li].grad, None), 0.0, c.workspace,
-                                          self.W[li], None)
+                    self.deferred.add_group(self.tn_groups[ti], tn_ph)
         if self.side is not None and full:
             torch.cuda.current_stream().wait_stream(self.side)
         if self.deferred is not None and full:

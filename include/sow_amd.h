@@ -55,7 +55,7 @@ const char* sow_error_string(int code);
 /* Kernel-selection switches -- for A/B measurements and for the tests that pin every kernel variant; production code
  * never touches them.  They are the library's ONLY process-wide state: a table of atomics initialised from the
  * environment (SOW_AMD_<NAME>) once, at first use; no launch path calls getenv.  Names: FORCE_CHAIN_V1, NO_SHORT_SPLIT,
- * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT
+ * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT, NO_TN_ROWS
  * (value 1 = on, -1 / 0 = off) and GEMM3S, GEMM3
  * (1 = force, 0 = forbid, -1 = automatic).  sow_set_switch returns SOW_ERR_UNSUPPORTED for an unknown name;
  * sow_get_switch returns the value (-1 / 0 / 1).  Changing a switch while other threads launch is safe (atomic) but
@@ -106,6 +106,10 @@ int sow_backward(const void* dy, const void* x, const void* h_save, const void* 
 #define SOW_BWD_WEIGHTS 2
 #define SOW_BWD_WEIGHTS_PARTIAL 4
 #define SOW_BWD_WEIGHTS_REDUCE 8
+/* sow_backward_group only: the token-slab counts of the weight-gradient partial sums may be planned over the whole group
+ * (row-owner kernel, see sow_backward_group) although the reduction is deferred; the deferred reduction must then be
+ * built with sow_backward_group_reduce_desc(same layers, same flag).  Implied when one call runs PARTIAL and REDUCE. */
+#define SOW_BWD_GROUP_SLABS 16
 int sow_backward_ex(const void* dy, const void* x, const void* h_save, const void* A, const void* B,
                     const void* acc_down, const void* acc_up, void* dx, void* dA, void* dB, void* dbias, int64_t T,
                     int d_in, int d_out, int r_live, int r_acc, int acc_kind, float scale, float grad_beta, int dtype,
@@ -158,6 +162,14 @@ typedef struct sow_layer_args {
 int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stream);
 /* phases as in sow_backward_ex; the phases run in order DATA (all layers), WEIGHTS_PARTIAL (all), WEIGHTS_REDUCE (all). */
 int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phases, void* stream);
+/* Weight gradients of a group: with enough layers to fill the chip (e.g. the 7 projections of a llama decoder block) the
+ * partial sums run in the ROW-OWNER kernel -- a workgroup owns all columns of a token slab, so h / dh are read once instead
+ * of once per 128 columns and x / dY arrive as whole rows -- with slab counts planned over the group (equal work per
+ * workgroup, one resident round; a pure function of the layer list).  The sums are then added in a different (still
+ * fixed) order than by n single calls: dA / dB / dbias agree with them to fp32 rounding of the slab sums, not bit for bit.
+ * sow_backward_group_reduce_desc: the descriptors (n x sow_reduce_desc_bytes(), HOST memory) and block counts of the
+ * deferred reductions of exactly this group, for sow_reduce_batch; `phases` = the flags of the PARTIAL call. */
+int sow_backward_group_reduce_desc(const sow_layer_args* layers, int n, int dtype, int phases, void* descs_out, int* blocks_out);
 
 /* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
  * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call

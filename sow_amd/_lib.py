@@ -18,6 +18,7 @@ F32, BF16 = 0, 1
 ACC_NONE, ACC_LOWRANK, ACC_DENSE = 0, 1, 2
 H_COLS = 64
 BWD_DATA, BWD_WEIGHTS, BWD_WEIGHTS_PARTIAL, BWD_WEIGHTS_REDUCE = 1, 2, 4, 8
+BWD_GROUP_SLABS = 16     # sow_backward_group: slab counts planned over the group (deferred reduction from group descriptors)
 
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
                                     c_void_p, c_size_t, c_int, c_void_p]),
     "sow_forward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_void_p]),
     "sow_backward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p]),
+    "sow_backward_group_reduce_desc": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p, POINTER(c_int)]),
     "sow_accumulate_batch": (c_int, [POINTER(AccumulateArgs), c_int, c_int, c_void_p]),
     "sow_reduce_desc_bytes": (c_size_t, []),
     "sow_backward_reduce_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int,

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 // ---- kernel-selection switches (common.hpp: enum Switch) ----------------------------------------------
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
-                                                   "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT"};
+                                                   "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
+                                                   "NO_TN_ROWS"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -117,7 +118,7 @@ static int gemm_auto(const void* A, int64_t lda, const void* B, int64_t ldb, boo
 
 extern "C" {
 
-int sow_version(void) { return 110; }
+int sow_version(void) { return 111; }
 
 int sow_set_switch(const char* name, int value) {
   if (!name) return SOW_ERR_NULL;
@@ -164,6 +165,7 @@ size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_l
 struct WsPlan {
   size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, total;
   int ns, slab_len;
+  int ns_cap;   // slabs the partial regions can hold (group-planned slab counts may exceed the single-layer choice)
 };
 static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
   WsPlan w{};
@@ -180,10 +182,15 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   if (r_live <= 64) {
     const int cg_in = (d_in + 63) / 64, cg_out = (d_out + 63) / 64;
     w.ns = tn_pick_slabs(T, cg_in + cg_out, (cg_in + 1) / 2 + (cg_out + 1) / 2, dtype, &w.slab_len);
+    w.ns_cap = w.ns;
+    if (dtype == SOW_BF16 && T >= 1024) {
+      const int by_len = (int)(T / 512 < TNR_MAX_SLABS ? T / 512 : TNR_MAX_SLABS);
+      if (by_len > w.ns_cap) w.ns_cap = by_len;
+    }
     w.off_p0 = off;
-    off += al256(tn_partial_bytes(w.ns, d_in));
+    off += al256(tn_partial_bytes(w.ns_cap, d_in));
     w.off_p1 = off;
-    off += al256(tn_partial_bytes(w.ns, d_out));
+    off += al256(tn_partial_bytes(w.ns_cap, d_out));
   }
   w.total = off;
   return w;
@@ -523,6 +530,26 @@ static bool group_chain_params(const sow_layer_args& L, bool bwd, int dtype, con
   return true;
 }
 
+// Group-planned slab counts for the weight-gradient partial sums (skinny_tn.hip: tn_partial_rows_kernel).  A pure function
+// of the layer list, so that sow_backward_group and sow_backward_group_reduce_desc agree.  Items 2 i, 2 i + 1 = the two
+// operands (x with dh, dY with h) of layer i.
+static bool group_rows_plan(const sow_layer_args* layers, int n, int dtype, int* ns, int* slab_len) {
+  if (dtype != SOW_BF16 || n < 1 || n > TN_MAXG) return false;
+  int64_t T[TNR_MAXI];
+  int D[TNR_MAXI], cap[TNR_MAXI];
+  for (int i = 0; i < n; ++i) {
+    const sow_layer_args& L = layers[i];
+    if (L.T <= 0 || L.r_live > 64 || (L.dbias && L.r_live > 63)) return false;
+    const WsPlan w = plan_ws(L.T, L.d_in, L.d_out, L.r_live, L.acc_kind == SOW_ACC_LOWRANK ? L.r_acc : 0, L.acc_kind, dtype);
+    if (L.workspace_bytes < w.total + 255) return false;
+    if (L.d_in % 8 || L.d_out % 8 || !al16p(L.x) || !al16p(L.dy) || !al16p(L.h_save)) return false;
+    T[2 * i] = T[2 * i + 1] = L.T;
+    D[2 * i] = L.d_in, D[2 * i + 1] = L.d_out;
+    cap[2 * i] = cap[2 * i + 1] = w.ns_cap;
+  }
+  return tn_rows_plan(T, D, cap, 2 * n, ns, slab_len);
+}
+
 static int check_layer(const sow_layer_args& L, bool bwd) {
   if (L.T < 0 || L.d_in <= 0 || L.d_out <= 0 || L.r_live <= 0) return SOW_ERR_SHAPE;
   if (L.T == 0) return SOW_OK;
@@ -628,7 +655,24 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
     if (ng && (rc = launch_gemm2h_group(gbatch, ng, true, stream))) return rc;
     if (nb && (rc = launch_chain2_group(batch, nb, true, stream))) return rc;
   }
-  if (do_partial) {
+  // row-owner weight-gradient kernel with slab counts planned over the group: when the caller asks for it (and then builds
+  // the deferred reduction from sow_backward_group_reduce_desc), or when this call runs the reduction itself
+  int rns[TNR_MAXI], rslab[TNR_MAXI];
+  const bool rows = (do_partial || do_reduce) && ((phases & SOW_BWD_GROUP_SLABS) || (do_partial && do_reduce)) &&
+                    group_rows_plan(layers, n, dtype, rns, rslab);
+  if (do_partial && rows) {
+    TnRowsItem items[TNR_MAXI];
+    for (int i = 0; i < n; ++i) {
+      const sow_layer_args& L = layers[i];
+      const WsPlan w = plan(L);
+      char* ws = ws_base(L.workspace);
+      items[2 * i] = TnRowsItem{L.x, ws + w.off_dh, (float*)(ws + w.off_p0), (int64_t)L.d_in, L.T, L.d_in, 0, 0, 0, 0, rns[2 * i],
+                                rslab[2 * i], 0};
+      items[2 * i + 1] = TnRowsItem{L.dy, L.h_save, (float*)(ws + w.off_p1), (int64_t)L.d_out, L.T, L.d_out, 0, 0, 0, 0,
+                                    rns[2 * i + 1], rslab[2 * i + 1], 0};
+    }
+    if ((rc = launch_tn_rows(items, 2 * n, stream))) return rc;
+  } else if (do_partial) {
     TnParams batch[TN_MAXG];
     int nb = 0;
     for (int i = 0; i < n; ++i) {
@@ -662,9 +706,43 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
     }
     if (nb && (rc = launch_tn_group(batch, nb, stream))) return rc;
   }
-  if (do_reduce)
+  if (do_reduce && rows) {
+    for (int i = 0; i < n; ++i) {
+      const sow_layer_args& L = layers[i];
+      ReduceParams rp = make_reduce_params(plan(L), ws_base(L.workspace), L.dA, L.dB, L.dbias, L.d_in, L.d_out, L.r_live, L.grad_beta);
+      rp.job[0].ns = rns[2 * i], rp.job[1].ns = rns[2 * i + 1];
+      if ((rc = launch_tn_reduce(rp, dtype, stream))) return rc;
+    }
+  } else if (do_reduce) {
     for (int i = 0; i < n; ++i)
       if (layers[i].T != 0 && (rc = single(layers[i], SOW_BWD_WEIGHTS_REDUCE))) return rc;
+  }
+  return SOW_OK;
+}
+
+int sow_backward_group_reduce_desc(const sow_layer_args* layers, int n, int dtype, int phases, void* descs_out, int* blocks_out) {
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return SOW_OK;
+  if (!layers || !descs_out || !blocks_out) return SOW_ERR_NULL;
+  int rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = check_layer(layers[i], true))) return rc;
+  int rns[TNR_MAXI], rslab[TNR_MAXI];
+  const bool rows = (phases & SOW_BWD_GROUP_SLABS) && group_rows_plan(layers, n, dtype, rns, rslab);
+  for (int i = 0; i < n; ++i) {
+    const sow_layer_args& L = layers[i];
+    char* out = (char*)descs_out + (size_t)i * sizeof(ReduceParams);
+    if ((rc = sow_backward_reduce_desc(L.dA, L.dB, L.dbias, L.T, L.d_in, L.d_out, L.r_live, L.r_acc, L.acc_kind, L.grad_beta, dtype,
+                                       L.workspace, L.workspace_bytes, out, blocks_out + i)))
+      return rc;
+    if (rows) {
+      ReduceParams rp;
+      memcpy(&rp, out, sizeof rp);
+      rp.job[0].ns = rns[2 * i], rp.job[1].ns = rns[2 * i + 1];
+      memcpy(out, &rp, sizeof rp);
+    }
+  }
   return SOW_OK;
 }
 

@@ -78,6 +78,7 @@ struct ReduceJob {
   int transpose;
   int ones_col;
   float alpha, beta;
+  int ns;   // slab count of THIS job (group-planned slabs, tn_rows_plan); 0 = ReduceParams::ns
 };
 struct ReduceParams {
   ReduceJob job[2];
@@ -96,6 +97,29 @@ struct TnGroup {
   int n;
 };
 bool tn_group_supported(const TnParams& p, int dtype);
+// Row-owner weight-gradient kernel (skinny_tn.hip: tn_partial_rows_kernel): one item per (layer, operand); a workgroup
+// owns ALL columns of a token slab (up to 1024 per column range), so S (h / dh) is read once per range instead of once
+// per 128 columns.  The slab counts are planned over the whole group (work per block equal across items).
+struct TnRowsItem {
+  const void* M;      // [T, D] bf16, row pitch ldm
+  const void* S;      // [T, 64] bf16
+  float* partial;     // [ns][ncg * 64][64] fp32
+  int64_t ldm, T;
+  int D, ncg;         // columns, 64-column groups
+  int nr, gpr, cgw;   // column ranges, groups per range, groups per wave (1 or 2)
+  int ns, slab_len;
+  int start;          // first block of this item in the grid
+};
+constexpr int TNR_MAXI = 2 * TN_MAXG;
+struct TnRowsGroup {
+  TnRowsItem it[TNR_MAXI];
+  int n, total;
+};
+constexpr int TNR_MAX_SLABS = 40;   // workspace capacity per operand (api.hip: plan_ws)
+// n items (T[i] tokens x D[i] columns, at most cap[i] slabs): slab counts such that the blocks of the group fill one
+// resident round (256 workgroups) with equal work; false = this group does not suit the kernel (too few / too many blocks)
+bool tn_rows_plan(const int64_t* T, const int* D, const int* cap, int n, int* ns_out, int* slab_len_out);
+int launch_tn_rows(TnRowsItem* items, int n, hipStream_t stream);
 int launch_tn_group(const TnParams* ps, int n, hipStream_t stream);
 int launch_tn_reduce(ReduceParams p, int dtype, hipStream_t stream);
 int launch_tn_reduce_batch(const ReduceParams* descs, const int* starts, int n, int total_blocks, int dtype, hipStream_t stream);

@@ -552,6 +552,218 @@ __global__ __launch_bounds__(64 * TNW_WAVES, 1) void tn_partial_dma_wide_kernel(
 }
 
 // =================================================================================================
+// bf16 row-owner variant (grouped launches of whole decoder blocks): a workgroup owns ALL columns of its token slab.
+//
+// The column-owner kernels above re-read S (h / dh: 128 bytes per token) once per 128 columns of M -- on a 512-wide
+// operand that is 4 x 4 MB from L2 beside 33.5 MB from HBM, and M arrives as 256-byte pieces of 1-KiB rows
+// (tools/probe8.hip: 8.5 us for that pattern, 7.7 us when a workgroup reads whole rows and S once).  Here the eight waves
+// of a workgroup split the COLUMNS of a range of up to 16 column groups (1024 columns) and walk the same tokens in lock
+// step: every wave streams its own one or two [16 tok x 64 col] M images per k-step through a wave-private ring, the S
+// images of a stage are DMA'd once (by waves 7, 6, ...) into a shared ring, one raw s_barrier per stage.  No cross-wave
+// sum: a wave's accumulators are final for its columns and go straight to the partial buffer.
+// A stage is 32 tokens (one group per wave: two k-steps) or 16 tokens (two groups per wave): 4 KiB of M per wave either
+// way, 4 ring slots (3 stages = 100 KiB in flight per CU), 144 KiB of LDS, one workgroup per CU.
+// With every column in one block the grid cannot be filled from a single layer (26 blocks for 512 -> 512); the slab
+// counts are therefore planned over the whole grouped launch (tn_rows_plan: equal work per block, one resident round),
+// which also cuts the fp32 partial traffic (13 slabs instead of 32 for a 512-wide operand of llama_60m).
+// =================================================================================================
+constexpr int TNR_WAVES = 8;
+constexpr int TNR_DEPTH = 4;
+constexpr int TNR_MSLOT = 4096;   // per wave and stage: two [16][64] bf16 images
+constexpr int TNR_SSLOT = 4096;   // per stage: up to two [16][64] bf16 images of S
+constexpr int TNR_LDS = TNR_WAVES * TNR_DEPTH * TNR_MSLOT + TNR_DEPTH * TNR_SSLOT;   // 144 KiB
+
+__device__ __forceinline__ void tnr_wait(int n) {   // all but the n most recent DMA instructions of this wave have landed
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;   // 2 stages x 5 instructions
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int CGW>
+__device__ __forceinline__ void tnr_block(const TnRowsItem& J, const int b, char* smem, const int lane, const int w) {
+  constexpr int KS = 2 / CGW;      // 16-token k-steps per stage
+  constexpr int TOKS = 16 * KS;
+  const int range = b % J.nr, slab = b / J.nr;
+  const int g_lo = range * J.gpr + w * CGW;
+  int g_hi = (range + 1) * J.gpr;
+  if (g_hi > J.ncg) g_hi = J.ncg;
+  const int nmy = g_lo >= g_hi ? 0 : (g_hi - g_lo < CGW ? g_hi - g_lo : CGW);   // column groups of this wave
+  const int64_t t_begin = (int64_t)slab * J.slab_len;
+  int64_t t_end = t_begin + J.slab_len;
+  if (t_end > J.T) t_end = J.T;
+  const int nstage = t_begin < t_end ? (int)((t_end - t_begin + TOKS - 1) / TOKS) : 0;
+  const int sq = TNR_WAVES - 1 - w;        // S instruction of this wave (image sq >> 1, row half sq & 1)
+  const bool s_own = sq < 2 * KS;
+  const int ni = 2 * (CGW == 2 ? nmy : 2 * nmy) + (s_own ? 1 : 0);   // DMA instructions of this wave per stage
+
+  const bf16_t* Mg = (const bf16_t*)J.M;
+  const bf16_t* Sg = (const bf16_t*)J.S;
+  char* mring = smem + w * (TNR_DEPTH * TNR_MSLOT);
+  char* sring = smem + TNR_WAVES * TNR_DEPTH * TNR_MSLOT;
+  const char* zp = zero_page_for(lane);
+  const int drow = lane >> 3, dpc = lane & 7;
+
+  // running per-lane source pointers: instruction (image im, row half hf) of every stage
+  const char* mp[2][2];
+  int64_t mstep[2][2];
+  int mtok[2][2];
+#pragma unroll
+  for (int im = 0; im < 2; ++im)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int row = hf * 8 + drow;
+      const int lc = dpc ^ (((row >> 1) & 1) << 2);
+      const int grp = CGW == 2 ? g_lo + im : g_lo;
+      const int tok = (CGW == 2 ? 0 : im * 16) + row;
+      const bool ok = (CGW == 2 ? im < nmy : nmy > 0) && grp * TN_BD + lc * 8 < J.D;
+      mp[im][hf] = ok ? (const char*)(Mg + (t_begin + tok) * J.ldm + grp * TN_BD + lc * 8) : zp;
+      mstep[im][hf] = ok ? (int64_t)TOKS * J.ldm * 2 : 0;
+      mtok[im][hf] = tok;
+    }
+  const char* sp = zp;
+  int64_t sstep = 0;
+  int stok = 0;
+  if (s_own) {
+    const int row = (sq & 1) * 8 + drow;
+    const int lc = dpc ^ (((row >> 1) & 1) << 2);
+    stok = (sq >> 1) * 16 + row;
+    sp = (const char*)(Sg + (t_begin + stok) * 64 + lc * 8);
+    sstep = (int64_t)TOKS * 64 * 2;
+  }
+  auto issue = [&](int i) {   // strictly in order: the pointers are at stage i
+    const int64_t tt0 = t_begin + (int64_t)i * TOKS;
+    const bool whole = tt0 + TOKS <= t_end;   // wave-uniform
+    char* ms = mring + (i % TNR_DEPTH) * TNR_MSLOT;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+      if (CGW == 2 ? im < nmy : nmy > 0) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const void* src = mp[im][hf];
+          if (!whole && tt0 + mtok[im][hf] >= t_end) src = zp;
+          dma16(src, ms + (im * 2 + hf) * 1024);
+          mp[im][hf] += mstep[im][hf];
+        }
+      }
+    }
+    if (s_own) {
+      const void* src = sp;
+      if (!whole && tt0 + stok >= t_end) src = zp;
+      dma16(src, sring + (i % TNR_DEPTH) * TNR_SSLOT + sq * 1024);
+      sp += sstep;
+    }
+  };
+
+  f32x16 acc[CGW][2][2];   // [group][32-row tile of the group][S tile]
+#pragma unroll
+  for (int gi = 0; gi < CGW; ++gi)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[gi][a][c][i] = 0.f;
+
+  const int g = lane >> 4, jj = lane & 15, q4 = jj >> 2, pp = jj & 3, h = g >> 1;
+  uint32_t roff[2];   // transposed read of rows 8h + q (+512: rows 8h + 4 + q) of a [16][64] image, 32-column tile
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    const int row = 8 * h + q4;
+    const int col = tile * 32 + 16 * (g & 1) + 4 * pp;
+    const int pc = (col >> 3) ^ (((row >> 1) & 1) << 2);
+    roff[tile] = (uint32_t)(row * 128 + pc * 16 + (col & 7) * 2);
+  }
+  const uint32_t mring_a = lds_addr(mring), sring_a = lds_addr(sring);
+
+  const int pre = nstage < TNR_DEPTH - 1 ? nstage : TNR_DEPTH - 1;
+  for (int i = 0; i < pre; ++i) issue(i);
+#pragma unroll 1
+  for (int i = 0; i < nstage; ++i) {
+    const int newer = (nstage - 1 - i) < (TNR_DEPTH - 2) ? (nstage - 1 - i) : (TNR_DEPTH - 2);
+    tnr_wait(newer * ni);    // this wave's part of stage i has landed ...
+    raw_barrier();           // ... and so has everybody else's (S); all waves have finished stage i - 1
+    if (i + TNR_DEPTH - 1 < nstage) issue(i + TNR_DEPTH - 1);   // into the slots of stage i - 1
+    if (nmy == 0) continue;
+    const uint32_t ma = mring_a + (uint32_t)((i % TNR_DEPTH) * TNR_MSLOT);
+    const uint32_t sa = sring_a + (uint32_t)((i % TNR_DEPTH) * TNR_SSLOT);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x2 sl[2], sh[2], ml[CGW][2], mh[CGW][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t ad = sa + (uint32_t)(ks * 2048) + roff[c];
+        DS_READ_TR(sl[c], ad, 0);
+        DS_READ_TR(sh[c], ad, 512);
+      }
+#pragma unroll
+      for (int gi = 0; gi < CGW; ++gi)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const uint32_t ad = ma + (uint32_t)((CGW == 2 ? gi : ks) * 2048) + roff[a];
+          DS_READ_TR(ml[gi][a], ad, 0);
+          DS_READ_TR(mh[gi][a], ad, 512);
+        }
+      LGKM_WAIT0();
+      bf16x8 bfr[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bfr[c] = as_bf16x8(join2(sl[c], sh[c]));
+#pragma unroll
+      for (int gi = 0; gi < CGW; ++gi) {
+        if (gi < nmy) {   // wave-uniform; an image that is not this wave's holds stale data
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const bf16x8 af = as_bf16x8(join2(ml[gi][a], mh[gi][a]));
+            acc[gi][a][0] = mfma32(af, bfr[0], acc[gi][a][0]);
+            acc[gi][a][1] = mfma32(af, bfr[1], acc[gi][a][1]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // partial[slab][group * 64 + row][col]: accumulator (a, c) register reg of lane l = row a*32 + acc_row(reg, l), col c*32 + (l & 31)
+#pragma unroll
+  for (int gi = 0; gi < CGW; ++gi) {
+    if (gi < nmy) {
+      float* P = J.partial + ((int64_t)slab * J.ncg * TN_BD + (int64_t)(g_lo + gi) * TN_BD) * 64;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            P[(a * 32 + acc_row(reg, lane)) * 64 + c * 32 + (lane & 31)] = acc[gi][a][c][reg];
+    }
+  }
+  raw_barrier();   // end of block: every wave is done with the shared S ring before the next block's DMA refills it
+}
+
+__global__ __launch_bounds__(64 * TNR_WAVES, 1) void tn_partial_rows_kernel(const TnRowsGroup grp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  for (int blk = (int)blockIdx.x; blk < grp.total; blk += (int)gridDim.x) {
+    int item = 0;
+#pragma unroll
+    for (int i = 1; i < TNR_MAXI; ++i)
+      if (i < grp.n && blk >= grp.it[i].start) item = i;
+    int tt = (int)threadIdx.x;
+    asm volatile("" : "+v"(tt));   // keeps per-lane address arithmetic inside the iteration (see chain2.hip)
+    if (grp.it[item].cgw == 2) tnr_block<2>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w);
+    else tnr_block<1>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w);
+  }
+}
+
+// =================================================================================================
 // fp32 fast path: the same wave-private LDS-DMA rings with exact-fp32 MFMA (32x32x2).
 //
 // fp32 needs no transposed reads: the MFMA takes ONE token per lane-half, and with the tiles in their
@@ -937,6 +1149,7 @@ template <typename T> __device__ __forceinline__ void tn_reduce_body(const Reduc
     jid = 1;
   }
   const ReduceJob& J = p.job[jid];
+  const int ns = J.ns > 0 ? J.ns : p.ns;
   // 256 threads = 4 slab splits x 4 rows x 16 column quads; splits are summed through LDS in a fixed
   // order, so the result does not depend on scheduling
   __shared__ f32x4 red[4][64];
@@ -950,7 +1163,7 @@ template <typename T> __device__ __forceinline__ void tn_reduce_body(const Reduc
     // four loads in flight per thread (the kernel is a chain of dependent round trips otherwise); the summation
     // order per thread stays i = split, split + 4, ... so the result is unchanged
     int i = split;
-    for (; i + 12 < p.ns; i += 16) {
+    for (; i + 12 < ns; i += 16) {
       const f32x4 v0 = *(const f32x4*)(src + (int64_t)i * stride);
       const f32x4 v1 = *(const f32x4*)(src + (int64_t)(i + 4) * stride);
       const f32x4 v2 = *(const f32x4*)(src + (int64_t)(i + 8) * stride);
@@ -958,7 +1171,7 @@ template <typename T> __device__ __forceinline__ void tn_reduce_body(const Reduc
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = (((s[e] + v0[e]) + v1[e]) + v2[e]) + v3[e];
     }
-    for (; i < p.ns; i += 4) {
+    for (; i < ns; i += 4) {
       const f32x4 v = *(const f32x4*)(src + (int64_t)i * stride);
       s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
     }
@@ -1085,6 +1298,57 @@ int launch_tn_group(const TnParams* ps, int n, hipStream_t stream) {
   SOW_SET_MAX_LDS_ONCE(LDS, tn_partial_dma_wide_kernel);
   const int64_t grid = (sw_on(SW_NO_PERSIST) || total < 256) ? total : 256;   // one resident workgroup per CU
   hipLaunchKernelGGL(tn_partial_dma_wide_kernel, dim3((unsigned)grid), dim3(64 * TNW_WAVES), LDS, stream, g);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+bool tn_rows_plan(const int64_t* T, const int* D, const int* cap, int n, int* ns_out, int* slab_len_out) {
+  if (n <= 0 || n > TNR_MAXI || sw_on(SW_NO_TN_ROWS) || sw_on(SW_TN_NARROW) || sw_on(SW_NO_GROUPED)) return false;
+  double work = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (T[i] <= 0 || D[i] <= 0 || D[i] % 8) return false;
+    work += (double)T[i] * D[i];
+  }
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int ncg = (D[i] + 63) / 64, nr = (ncg + 15) / 16;
+    int ns = (int)(256.0 * (double)T[i] * D[i] / work) / nr;   // this item's share of one resident round
+    const int64_t max_ns = T[i] / 512 > 0 ? T[i] / 512 : 1;   // slabs of at least 512 tokens
+    if (ns > max_ns) ns = (int)max_ns;
+    if (ns < 1) ns = 1;
+    if (ns > TNR_MAX_SLABS) return false;                      // a small group: the column-owner kernel fills the chip better
+    int64_t len = (T[i] + ns - 1) / ns;
+    len = (len + 31) / 32 * 32;
+    ns = (int)((T[i] + len - 1) / len);
+    if (ns > cap[i]) return false;
+    ns_out[i] = ns, slab_len_out[i] = (int)len;
+    total += ns * nr;
+  }
+  return total >= 160 && total <= 256;
+}
+
+int launch_tn_rows(TnRowsItem* items, int n, hipStream_t stream) {
+  if (n <= 0) return SOW_OK;
+  if (n > TNR_MAXI) return SOW_ERR_SHAPE;
+  TnRowsGroup g{};
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    TnRowsItem& it = items[i];
+    if ((reinterpret_cast<uintptr_t>(it.M) & 15) || (reinterpret_cast<uintptr_t>(it.S) & 15) || it.ldm % 8 || it.D % 8 ||
+        it.slab_len % 32 || it.ns < 1)
+      return SOW_ERR_ALIGN;
+    it.ncg = (it.D + 63) / 64;
+    it.nr = (it.ncg + 15) / 16;
+    it.gpr = (it.ncg + it.nr - 1) / it.nr;
+    it.cgw = it.gpr > TNR_WAVES ? 2 : 1;
+    it.start = total;
+    total += it.ns * it.nr;
+    g.it[i] = it;
+  }
+  g.total = total;
+  SOW_SET_MAX_LDS_ONCE(TNR_LDS, tn_partial_rows_kernel);
+  hipLaunchKernelGGL(tn_partial_rows_kernel, dim3((unsigned)(total < 256 ? total : 256)), dim3(64 * TNR_WAVES), TNR_LDS, stream, g);
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }

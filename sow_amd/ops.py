@@ -222,7 +222,9 @@ class LayerCall:
 
 class LayerGroup:
     """n independent layer calls issued through sow_forward_group / sow_backward_group: layers on the bf16 streaming
-    kernels share launches (q / k / v; gate / up).  Results are bit-identical to n single calls."""
+    kernels share launches (q / k / v; gate / up).  Outputs, input gradients and saved projections are bit-identical to n
+    single calls; the weight gradients of a group large enough for the row-owner kernel (a whole decoder block) are summed
+    over differently cut token slabs and agree to fp32 rounding of those sums."""
 
     def __init__(self, calls: Sequence[LayerCall]):
         if not calls:
@@ -239,6 +241,17 @@ class LayerGroup:
     def backward(self, phases: int = _lib.BWD_DATA | _lib.BWD_WEIGHTS) -> None:
         _launch(self.device, "sow_backward_group", _lib.load().sow_backward_group, self.arr, len(self.calls), self.dtype,
                 int(phases))
+
+    def reduce_descs(self, phases: int):
+        """Descriptors and block counts of the deferred weight-gradient reductions of this group (sow_reduce_batch), for a
+        PARTIAL phase issued with the same `phases` flags (BWD_GROUP_SLABS included or not)."""
+        lib = _lib.load()
+        n, size = len(self.calls), lib.sow_reduce_desc_bytes()
+        buf = ctypes.create_string_buffer(size * n)
+        blocks = (ctypes.c_int * n)()
+        _lib.check(lib.sow_backward_group_reduce_desc(self.arr, n, self.dtype, int(phases), buf, blocks),
+                   "sow_backward_group_reduce_desc")
+        return [buf.raw[i * size:(i + 1) * size] for i in range(n)], list(blocks)
 
 
 class DeferredReduce:
@@ -280,6 +293,23 @@ class DeferredReduce:
         self._descs.append(buf.raw)
         self._blocks.append(nb.value)
         self._dev, self._dt = x2.device, _dt(x2)
+
+    def add_group(self, group: "LayerGroup", phases: int):
+        """Register (or re-validate) every layer of a group whose PARTIAL phase was just enqueued with `phases`."""
+        n = len(group.calls)
+        key = ("group", id(group), int(phases), bytes(group.arr))
+        i = self._pos
+        self._pos += n
+        if i + n <= len(self._keys) and all(self._keys[i + k] == (key, k) for k in range(n)):
+            return
+        del self._keys[i:], self._descs[i:], self._blocks[i:]
+        self._d_descs = None
+        descs, blocks = group.reduce_descs(phases)
+        for k in range(n):
+            self._keys.append((key, k))
+            self._descs.append(descs[k])
+            self._blocks.append(blocks[k])
+        self._dev, self._dt = group.device, group.dtype
 
     def run(self):
         """One launch for every layer added since the last run()."""

@@ -391,8 +391,11 @@ def test_grouped_calls_are_bit_identical_to_single_calls(case):
         dx1, dA1, dB1, _ = ops.sow_backward(dy, x, h1, A, B, W, None, 0.75, False)
         singles.append((y1, h1, dx1, dA1, dB1))
     grp = ops.LayerGroup(calls)
-    grp.forward()
-    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    # NO_TN_ROWS: a group with enough layers may take the row-owner weight-gradient kernel, whose slab sums are cut
+    # differently (test_block_weight_gradients_row_owner_kernel); the column-owner kernels are bit-identical to single calls
+    with _lib.switch(NO_TN_ROWS=1):
+        grp.forward()
+        grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
     torch.cuda.synchronize()
     for c, (y1, h1, dx1, dA1, dB1) in zip(calls, singles):
         r = c.args.r_live
@@ -400,6 +403,12 @@ def test_grouped_calls_are_bit_identical_to_single_calls(case):
         assert torch.equal(c.y, y1) and torch.equal(hv[:, :r], h1v[:, :r]) and torch.equal(hv[:, 63], h1v[:, 63])
         assert torch.equal(c.dx, dx1)
         assert torch.equal(c._keep[7], dA1) and torch.equal(c._keep[8], dB1)
+    # default switches: same outputs and input gradients; weight gradients to rounding
+    grp.forward()
+    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    for c, (y1, h1, dx1, dA1, dB1) in zip(calls, singles):
+        assert torch.equal(c.y, y1) and torch.equal(c.dx, dx1)
+        assert rel_err(c._keep[7].float().cpu(), dA1.float().cpu()) < 1e-2 and rel_err(c._keep[8].float().cpu(), dB1.float().cpu()) < 1e-2
     # the same with the grouping switched off (layer-by-layer through the group entry point)
     with _lib.switch(NO_GROUPED=1):
         for c in calls:
@@ -408,6 +417,70 @@ def test_grouped_calls_are_bit_identical_to_single_calls(case):
         grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
     for c, (y1, _, dx1, dA1, _) in zip(calls, singles):
         assert torch.equal(c.y, y1) and torch.equal(c.dx, dx1) and torch.equal(c._keep[7], dA1)
+
+
+@pytest.mark.parametrize("T", [8192, 8200, 32768])
+def test_block_weight_gradients_row_owner_kernel(T):
+    """The 7 projections of a llama_60m decoder block in ONE weight-gradient launch: the row-owner kernel (a workgroup owns
+    all columns of a token slab; slab counts planned over the group) against a float64 reference of dA = x^T dh,
+    dB = h^T dY, dbias = colsum(dY) built from the kernel's own bf16 h / dh, and against the per-layer calls; the deferred
+    form (PARTIAL with BWD_GROUP_SLABS + sow_backward_group_reduce_desc + sow_reduce_batch) is bit-identical to the
+    one-call form.  A 768-wide layer (12 column groups: two per wave) and biases ride along."""
+    from sow_amd import _lib, ops
+    specs = [(512, 512, False)] * 3 + [(512, 512, True), (512, 1376, False), (512, 1376, True), (1376, 512, False)]
+    if T == 8200:
+        specs = specs[:5] + [(768, 768, True), (1376, 512, False)]
+    r = 50
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    calls, ref = [], []
+    for (di, do, has_bias) in specs:
+        x = torch.randn(T, di, generator=gen, device=DEV).bfloat16()
+        dy = torch.randn(T, do, generator=gen, device=DEV).bfloat16()
+        A = (torch.randn(di, r, generator=gen, device=DEV) * 0.05).bfloat16()
+        B = (torch.randn(r, do, generator=gen, device=DEV) * 0.05).bfloat16()
+        bias = torch.zeros(do, device=DEV, dtype=torch.bfloat16) if has_bias else None
+        out = (torch.zeros_like(A), torch.zeros_like(B), torch.zeros_like(bias) if has_bias else None)
+        calls.append(ops.LayerCall(x, A, B, bias=bias, scale=0.5, dy2=dy, dx=torch.empty_like(x), out=out, grad_beta=0.0))
+        y1, h1 = ops.sow_forward(x, A, B, None, None, bias, 0.5)
+        _, dA1, dB1, db1 = ops.sow_backward(dy, x, h1, A, B, None, None, 0.5, has_bias)
+        ref.append((x, dy, A, B, dA1, dB1, db1))
+    grp = ops.LayerGroup(calls)
+    grp.forward()
+    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)          # PARTIAL and REDUCE in one call: group-planned slabs
+    torch.cuda.synchronize()
+    one_call = [(c._keep[7].clone(), c._keep[8].clone(), None if c._keep[9] is None else c._keep[9].clone()) for c in calls]
+    worst = 0.0
+    for c, (x, dy, A, B, dA1, dB1, db1), (dA, dB, db) in zip(calls, ref, one_call):
+        h = c.h.view(-1, 64)[:, :r].double()                                   # scaled bf16 h as saved by the forward kernel
+        dh = (0.5 * (dy.double() @ B.double().t())).bfloat16().double()        # what the data-gradient kernel leaves for dA
+        dA64, dB64 = x.double().t() @ dh, h.t() @ dy.double()
+        for got, single, want in ((dA, dA1, dA64), (dB, dB1, dB64)):
+            e_rows, e_single = rel_err(got.double().cpu(), want.cpu()), rel_err(single.double().cpu(), want.cpu())
+            assert e_rows < 6e-3 and e_rows < 1.5 * e_single + 1e-3, (tuple(got.shape), e_rows, e_single)
+            worst = max(worst, e_rows)
+        if db is not None:
+            assert rel_err(db.double().cpu(), dy.double().sum(0).cpu()) < 6e-3
+            assert rel_err(db.double().cpu(), db1.double().cpu()) < 1e-2
+    # deferred reduction built from the group's own descriptors
+    for c in calls:
+        for g_ in c._keep[7:10]:
+            if g_ is not None:
+                g_.zero_()
+    ph = _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS
+    grp.backward(ph)
+    red = ops.DeferredReduce()
+    red.add_group(grp, ph)
+    red.run()
+    torch.cuda.synchronize()
+    for c, (dA, dB, db) in zip(calls, one_call):
+        assert torch.equal(c._keep[7], dA) and torch.equal(c._keep[8], dB)
+        assert db is None or torch.equal(c._keep[9], db)
+    # and with the kernel switched off the group is bit-identical to the per-layer calls again
+    with _lib.switch(NO_TN_ROWS=1):
+        grp.backward(_lib.BWD_WEIGHTS)
+    for c, (_, _, _, _, dA1, dB1, _) in zip(calls, ref):
+        assert torch.equal(c._keep[7], dA1) and torch.equal(c._keep[8], dB1)
+
 
 
 # ---------------------------------------------------------------------------------------------
