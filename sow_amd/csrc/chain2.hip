@@ -83,7 +83,7 @@ template <bool TR> __device__ __forceinline__ int img_chunk(int row, int c) {
 // 5.1 TB/s), so three 512-workgroup layers in one 1536-workgroup grid pay it once; later rounds start while earlier
 // workgroups drain.  Every workgroup runs exactly the single-layer code on its own layer's parameter block, so the
 // results are bit-identical to separate launches.
-template <bool BWD>
+template <bool BWD, bool P16>
 __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid, char* smem, const int t, const int lane, const int w,
                                              uint64_t* stamps) {
   constexpr bool TR = !BWD;
@@ -507,6 +507,40 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
       }
     }
   };
+  // bf16 park tiles ([32 tok][64 col] bf16, 4 KiB, three of them in ring slots 3..5): with no bias and beta = 0 the value
+  // stored is exactly bf16(acc), so the rounding can be done before the transposition -- half the LDS traffic of the
+  // epilogue, one ds_read_b128 per 16-byte store, and ring slots 0..2 stay free during phase 2
+  constexpr bool park16 = P16;   // host-selected instantiation: every layer of the launch has pair_flush, beta = 0 and no bias
+  auto tile16_addr = [&](int buf, int row, int chunk) {   // chunk = 16-byte (8 bf16) index 0..7
+    return ring_a + (uint32_t)(3 * C2_STAGE + buf * 4096 + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16));
+  };
+  auto store16 = [&](int r, int col, u32x4 ov) {
+    const int64_t tk = tok0 + r;
+    if (tk < p.M && col < D2) {
+      bf16_t* dst = Y + tk * p.ldy + col;
+      if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(ov) : "memory");
+      else *(u32x4*)dst = ov;
+    }
+  };
+  auto flush16 = [&](int sl_prev) {   // one slice: rows 16*hh .. 16*hh+15, 128 bytes per row
+    u32x4 v[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) DS_READ_B128(v[pass], tile16_addr(sl_prev % 3, 16 * hh + pass * 8 + (lane >> 3), lane & 7), 0);
+    LGKM_WAIT0();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) store16(16 * hh + pass * 8 + (lane >> 3), (sl0 + sl_prev) * 64 + (lane & 7) * 8, v[pass]);
+  };
+  auto flush_pair16 = [&](int sl_a) {   // two slices: 256 bytes per row
+    u32x4 v[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = 16 * hh + ps * 4 + (lane >> 4), c16 = lane & 15;
+      DS_READ_B128(v[ps], tile16_addr((sl_a + (c16 >> 3)) % 3, r, c16 & 7), 0);
+    }
+    LGKM_WAIT0();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) store16(16 * hh + ps * 4 + (lane >> 4), (sl0 + sl_a) * 64 + (lane & 15) * 8, v[ps]);
+  };
 #pragma unroll 1
   for (int sl = 0; sl < nsl; ++sl) {
     raw_barrier();   // factor chunk nst + sl is in its slot; the partner has parked slice sl-1
@@ -536,6 +570,15 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     for (int ks = 0; ks < 4; ++ks)
       if (ks < ksteps) yacc = mfma32(as_bf16x8(join2(bl[ks], bh[ks])), as_bf16x8(hf[ks]), yacc);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (park16) {
+      if (sl >= 2 && !(sl & 1)) flush_pair16(sl - 2);
+      // park: register quad rq = columns hh*32 + 8*rq + 4*lh .. +3 of token li = half lh of 16-byte chunk hh*4 + rq
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const u32x2 v = {pack_bf16x2(yacc[4 * rq + 0], yacc[4 * rq + 1]), pack_bf16x2(yacc[4 * rq + 2], yacc[4 * rq + 3])};
+        *(u32x2*)(ring + 3 * C2_STAGE + (sl % 3) * 4096 + li * 128 + (((hh * 4 + rq) ^ ((li >> 1) & 7)) * 16) + lh * 8) = v;
+      }
+    } else {
     if (pairf) {
       if (sl >= 2 && !(sl & 1)) flush_pair(sl - 2);   // the previous two slices, while this slice's MFMAs drain
     } else if (sl > 0) {
@@ -548,12 +591,18 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
       f32x4 v = {yacc[4 * rq + 0], yacc[4 * rq + 1], yacc[4 * rq + 2], yacc[4 * rq + 3]};
       *(f32x4*)(ring + (pairf ? sl % 3 : (sl & 1)) * 8192 + li * 256 + ((chunk ^ (li & 15)) * 16)) = v;
     }
+    }
   }
   C2_STAMP(4);
   if (nsl > 0) {
     raw_barrier();   // the partner has parked the last slice
-    if (pairf && nsl >= 2 && !(nsl & 1)) flush_pair(nsl - 2);
-    else flush(nsl - 1);   // (pair mode, odd count: the pairs before it went out inside the loop)
+    if constexpr (park16) {
+      if (nsl >= 2 && !(nsl & 1)) flush_pair16(nsl - 2);
+      else flush16(nsl - 1);
+    } else {
+      if (pairf && nsl >= 2 && !(nsl & 1)) flush_pair(nsl - 2);
+      else flush(nsl - 1);   // (pair mode, odd count: the pairs before it went out inside the loop)
+    }
   }
   C2_STAMP(5);
   raw_barrier();     // end of block: every LDS read of this block has returned -- the next block's DMA may overwrite the rings
@@ -569,7 +618,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
 // round.  A resident workgroup issues the next block's first loads right after its last stores: the store drain and
 // the load latency overlap, and nothing is relaunched.  Every block runs exactly the single-layer code on its own
 // layer's parameter block, so the results are bit-identical to separate launches.
-template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(const ChainGroup grp) {   // 4 waves per SIMD: caps the allocation at 128 VGPRs, above which a CU cannot place two of these workgroups
+template <bool BWD, bool P16> __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kernel(const ChainGroup grp) {   // 4 waves per SIMD: caps the allocation at 128 VGPRs, above which a CU cannot place two of these workgroups
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -583,7 +632,7 @@ template <bool BWD> __global__ __launch_bounds__(C2_THREADS, 4) void chain2_kern
     // loop by LICM it stays live across the whole block (168 VGPRs instead of ~100; above 128 a CU holds one workgroup)
     int tt = t;
     asm volatile("" : "+v"(tt));
-    chain2_block<BWD>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w, grp.stamps ? grp.stamps + (int64_t)blk * 8 : nullptr);
+    chain2_block<BWD, P16>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w, grp.stamps ? grp.stamps + (int64_t)blk * 8 : nullptr);
   }
 }
 
@@ -677,13 +726,21 @@ int launch_chain2_group(const ChainParams* ps, int n, bool bwd, hipStream_t stre
   if (total > 0x7fffffff) return SOW_ERR_SHAPE;
   // persistent when the block list exceeds one resident round (two 80-KiB workgroups per CU x 256 CUs)
   const int64_t grid = (sw_on(SW_NO_PERSIST) || total < C2_RESIDENT) ? total : C2_RESIDENT;
+  bool p16 = !sw_on(SW_NO_PARK16);   // bf16 park tiles: exact only when the epilogue adds nothing to the rounded product
+  for (int i = 0; i < n; ++i) p16 = p16 && g.p[i].pair_flush && g.p[i].beta == 0.f && !g.p[i].bias;
+#define C2_LAUNCH(B, P)                                                                                              \
+  do {                                                                                                               \
+    SOW_SET_MAX_LDS_ONCE(C2_LDS, (chain2_kernel<B, P>));                                                             \
+    hipLaunchKernelGGL((chain2_kernel<B, P>), dim3((unsigned)grid), dim3(C2_THREADS), C2_LDS, stream, g);            \
+  } while (0)
   if (bwd) {
-    SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<true>);
-    hipLaunchKernelGGL(chain2_kernel<true>, dim3((unsigned)grid), dim3(C2_THREADS), C2_LDS, stream, g);
+    if (p16) C2_LAUNCH(true, true);
+    else C2_LAUNCH(true, false);
   } else {
-    SOW_SET_MAX_LDS_ONCE(C2_LDS, chain2_kernel<false>);
-    hipLaunchKernelGGL(chain2_kernel<false>, dim3((unsigned)grid), dim3(C2_THREADS), C2_LDS, stream, g);
+    if (p16) C2_LAUNCH(false, true);
+    else C2_LAUNCH(false, false);
   }
+#undef C2_LAUNCH
   SOW_CHECK_LAUNCH();
   return SOW_OK;
 }
