@@ -40,7 +40,9 @@
 namespace sow {
 
 // In-kernel timeline (debug builds only: `make STAMPS=1` -> libsow_amd_stamps.so, tools/chain_stamps.py): wave 0 of every
-// workgroup writes s_memrealtime (100 MHz) at the phase boundaries of every block it runs into grp.stamps[block][8].
+// workgroup writes s_memrealtime (100 MHz) at the phase boundaries of every block it runs into grp.stamps[block][16]
+// (slots 0-6); slots 8-12 hold accumulated wait times (10-ns ticks): 8 loader wave 4 in its counted DMA wait, 9 the same wave at the chunk barrier, 10 / 11 compute wave 0 in its X wait / at the stage barrier of
+// phase 1, 12 compute wave 0 at the slice barrier of phase 2.
 #ifdef SOW_STAMPS
 #define C2_STAMP(i)                                                                                  \
   do {                                                                                               \
@@ -49,6 +51,20 @@ namespace sow {
 #else
 #define C2_STAMP(i) \
   do {              \
+  } while (0)
+#endif
+#ifdef SOW_STAMPS
+#define C2_TICK() __builtin_amdgcn_s_memrealtime()
+#define C2_ACC(var, t0) var += __builtin_amdgcn_s_memrealtime() - (t0)
+#define C2_PUT(cond, i, var)                     \
+  do {                                           \
+    if (stamps && (cond) && lane == 0) stamps[i] = (var); \
+  } while (0)
+#else
+#define C2_TICK() 0ull
+#define C2_ACC(var, t0) (void)(t0)
+#define C2_PUT(cond, i, var) \
+  do {                       \
   } while (0)
 #endif
 
@@ -137,6 +153,9 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     const bool b_ragged = (cols_b & 63) != 0;
     const int nb_chunks = (cols_b + 63) / 64;
     auto issue = [&](int c) {
+#ifdef C2_EXPERIMENT_NO_FACTOR_DMA   // timing experiment only (wrong results): what the factor re-reads from L2 cost
+      if (c >= C2_NSLOT) return;
+#endif
       char* slot = smem + (c % C2_NSLOT) * C2_FSLOT;
       const int ci = c < nst ? st0 + c : sl0 + (c - nst);   // chunk index inside its matrix
       if (chunk_is_a(c)) {
@@ -158,9 +177,12 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     };
     const int pre = total < C2_AHEAD ? total : C2_AHEAD;
     for (int c = 0; c < pre; ++c) issue(c);
+    uint64_t tw_dma = 0, tw_bar = 0;
     for (int c = 0; c < total; ++c) {
       const int newer = (total - 1 - c) < (C2_AHEAD - 1) ? (total - 1 - c) : (C2_AHEAD - 1);
+      const uint64_t tk0 = C2_TICK();
       wait_groups<C2_LPW>(newer);
+      C2_ACC(tw_dma, tk0);
       // fix-up: rewrite the last row of A (its DMA pieces past the end of the buffer were zero-filled)
       if (chunk_is_a(c)) {
         const int base = (c < nst ? st0 + c : sl0 + (c - nst)) * 64;
@@ -174,9 +196,13 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
         raw_barrier();
         raw_barrier();
       }
+      const uint64_t tk1 = C2_TICK();
       raw_barrier();   // chunk c visible to the consumers; they have finished chunk c-1
+      C2_ACC(tw_bar, tk1);
       if (c + C2_AHEAD < total) issue(c + C2_AHEAD);   // its slot held chunk c-1: every consumer finished it before barrier c
     }
+    C2_PUT(w == C2_NCW, 8, tw_dma);
+    C2_PUT(w == C2_NCW, 9, tw_bar);
     if (nsl > 0) {
       raw_barrier();   // matches the compute waves' final "last slice parked" barrier
     } else {           // H-only call (D2 == 0): the hand-off barriers were not met inside the loop
@@ -275,12 +301,17 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   for (int st = 0; st < pre; ++st) issue_x(st);
 
   // ================================================================== phase 1: H^T = F1^T . X^T (K half hh)
+  uint64_t tw_x = 0, tw_b1 = 0, tw_b2 = 0;
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
     // stages issued after `st` at this point: st+1 .. st+DEPTH-2
     const int newer = (nst - 1 - st) < (C2_DEPTH - 2) ? (nst - 1 - st) : (C2_DEPTH - 2);
+    const uint64_t tk0 = C2_TICK();
     wait_groups<2>(newer);   // this wave's half of X stage `st` has landed
+    C2_ACC(tw_x, tk0);
+    const uint64_t tk1 = C2_TICK();
     raw_barrier();           // ... and so have the partner's half and factor chunk `st`
+    C2_ACC(tw_b1, tk1);
     if (st == 0) C2_STAMP(1);
     if (st + C2_DEPTH - 1 < nst) issue_x(st + C2_DEPTH - 1);   // into the slot of stage st-1
     const uint32_t xs = ring_a + (uint32_t)((st % C2_DEPTH) * C2_STAGE) + xoff;
@@ -543,7 +574,9 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   };
 #pragma unroll 1
   for (int sl = 0; sl < nsl; ++sl) {
+    const uint64_t tk2 = C2_TICK();
     raw_barrier();   // factor chunk nst + sl is in its slot; the partner has parked slice sl-1
+    C2_ACC(tw_b2, tk2);
     const uint32_t fs = slot_a + (uint32_t)(((nst + sl) % C2_NSLOT) * C2_FSLOT) + foff2;
     u32x2 bl[4], bh[4];
     if constexpr (TR) {
@@ -607,6 +640,9 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   C2_STAMP(5);
   raw_barrier();     // end of block: every LDS read of this block has returned -- the next block's DMA may overwrite the rings
   C2_STAMP(6);
+  C2_PUT(w == 0, 10, tw_x);
+  C2_PUT(w == 0, 11, tw_b1);
+  C2_PUT(w == 0, 12, tw_b2);
 }
 
 // Grouped, persistent launch: the grid is min(total, C2_RESIDENT) workgroups (two per CU); workgroup g runs token blocks
@@ -632,7 +668,7 @@ template <bool BWD, bool P16> __global__ __launch_bounds__(C2_THREADS, 4) void c
     // loop by LICM it stays live across the whole block (168 VGPRs instead of ~100; above 128 a CU holds one workgroup)
     int tt = t;
     asm volatile("" : "+v"(tt));
-    chain2_block<BWD, P16>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w, grp.stamps ? grp.stamps + (int64_t)blk * 8 : nullptr);
+    chain2_block<BWD, P16>(grp.p[layer], blk - grp.start[layer], smem, tt, tt & 63, w, grp.stamps ? grp.stamps + (int64_t)blk * 16 : nullptr);
   }
 }
 

@@ -30,7 +30,7 @@ for name, shapes, bwd in (("fwd q+k+v", [(512, 512)] * 3, False), ("fwd gate+up"
         calls.append(ops.LayerCall(x, A, B, dy2=dy, dx=torch.empty_like(x), out=(torch.zeros_like(A), torch.zeros_like(B), None)))
     grp = ops.LayerGroup(calls)
     nblk = len(shapes) * (T // 64)
-    buf = torch.zeros(nblk, 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nblk, 16, dtype=torch.int64, device=dev)
     run = (lambda: grp.backward(_lib.BWD_DATA)) if bwd else grp.forward
     if bwd:
         grp.forward()
@@ -41,9 +41,9 @@ for name, shapes, bwd in (("fwd q+k+v", [(512, 512)] * 3, False), ("fwd gate+up"
     run()
     torch.cuda.synchronize()
     set_stamps(None)
-    st = buf.cpu().double() * 0.01     # us
-    t0 = st[:, 0].min()
-    st = st - t0
+    raw = buf.cpu().double() * 0.01    # us
+    st = raw[:, :8] - raw[:, 0].min()
+    waits = raw[:, 8:13]
     print(f"== {name}: kernel span {float(st[:, 6].max()):.1f} us (first block start -> last block end)")
     for rnd in range(len(shapes)):
         s = st[rnd * 512:(rnd + 1) * 512]
@@ -51,3 +51,6 @@ for name, shapes, bwd in (("fwd q+k+v", [(512, 512)] * 3, False), ("fwd gate+up"
         print(f"  round {rnd}: start {float(s[:, 0].mean()):6.2f} +- {float(s[:, 0].std()):4.2f} (min {float(s[:, 0].min()):6.2f} max {float(s[:, 0].max()):6.2f}) | "
               f"first-load {seg[0]:5.2f} | phase1 {seg[1]:5.2f} | hand-off {seg[2]:5.2f} | phase2 {seg[3]:5.2f} | last-flush {seg[4]:5.2f} | end-barrier {seg[5]:5.2f} | "
               f"block {float((s[:, 6] - s[:, 0]).mean()):5.2f} us")
+        wv = waits[rnd * 512:(rnd + 1) * 512].mean(0)
+        print(f"           waits per block: loader wave in its DMA wait {float(wv[0]):5.2f} | loader at barriers {float(wv[1]):5.2f} | "
+              f"compute wave 0: X wait {float(wv[2]):5.2f}, phase-1 barriers {float(wv[3]):5.2f}, phase-2 barriers {float(wv[4]):5.2f} us")

@@ -37,7 +37,7 @@ for name, shapes, bwd in (("fwd o 1x(512->512)", [(512, 512)], False), ("fwd q+k
             B = (torch.randn(R, do, device=dev) * 0.04).bfloat16()
             calls.append(ops.LayerCall(x, A, B, dy2=dy, dx=torch.empty_like(x), out=(torch.zeros_like(A), torch.zeros_like(B), None)))
         groups.append(ops.LayerGroup(calls))
-        bufs.append(torch.zeros(len(shapes) * (T // 64), 8, dtype=torch.int64, device=dev))
+        bufs.append(torch.zeros(len(shapes) * (T // 64), 16, dtype=torch.int64, device=dev))
 
     def run_all():
         for g, b in zip(groups, bufs):
