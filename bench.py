@@ -518,7 +518,7 @@ def main():
         else:
             # dominant kernel (largest total time in profiles/): the forward chain kernel.  Algorithmic bytes per launch =
             # sum over the launch's layers of T*(d_in + d_out + r)*s (x read once, y written once, h saved once).
-            kernel_sym = "chain2_kernel<false>" if args.dtype == "bf16" else "chain2f_kernel<false>"
+            kernel_sym = "chain2_kernel<false, true>" if args.dtype == "bf16" else "chain2f_kernel<false>"   # <backward, bf16 park tiles>
             kname = f"sow::{kernel_sym} (fused forward chain{', fp32' if args.dtype != 'bf16' else ''})"
             nl = head["n_fwd_launches"]
             kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / nl

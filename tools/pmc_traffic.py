@@ -28,7 +28,7 @@ def per_kernel(d, counter):
 
 
 def short(name):
-    m = re.search(r"sow::([A-Za-z0-9_]+(?:<[a-z]+>)?)", name)
+    m = re.search(r"sow::([A-Za-z0-9_]+(?:<[a-z, ]+>)?)", name)
     return m.group(1) if m else name[:40]
 
 
