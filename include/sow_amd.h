@@ -170,6 +170,10 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
  * sow_backward_group_reduce_desc: the descriptors (n x sow_reduce_desc_bytes(), HOST memory) and block counts of the
  * deferred reductions of exactly this group, for sow_reduce_batch; `phases` = the flags of the PARTIAL call. */
 int sow_backward_group_reduce_desc(const sow_layer_args* layers, int n, int dtype, int phases, void* descs_out, int* blocks_out);
+/* What sow_backward_group(layers, n, dtype, phases) does for the weight gradients: returns 1 if the row-owner kernel with
+ * group-planned slabs runs, 0 if every layer keeps its single-layer slab count (negative: error); slabs_out (2 n ints,
+ * may be NULL) receives the token-slab counts of the x / dY operand of every layer. */
+int sow_backward_group_plan(const sow_layer_args* layers, int n, int dtype, int phases, int* slabs_out);
 
 /* General row-major GEMM  C[M,N] = alpha * op(A) op(B) + beta * C + bias[N]  (bias may be NULL).
  * trans_a: A is stored [K,M]; trans_b: B is stored [N,K].  Replaces the plain `@` / einsum call

@@ -57,6 +57,7 @@ SIGNATURES = {
     "sow_forward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_void_p]),
     "sow_backward_group": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p]),
     "sow_backward_group_reduce_desc": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, c_void_p, POINTER(c_int)]),
+    "sow_backward_group_plan": (c_int, [POINTER(LayerArgs), c_int, c_int, c_int, POINTER(c_int)]),
     "sow_accumulate_batch": (c_int, [POINTER(AccumulateArgs), c_int, c_int, c_void_p]),
     "sow_reduce_desc_bytes": (c_size_t, []),
     "sow_backward_reduce_desc": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int,

@@ -720,6 +720,31 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
   return SOW_OK;
 }
 
+int sow_backward_group_plan(const sow_layer_args* layers, int n, int dtype, int phases, int* slabs_out) {
+  if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
+  if (n < 0) return SOW_ERR_SHAPE;
+  if (n == 0) return 0;
+  if (!layers) return SOW_ERR_NULL;
+  int rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = check_layer(layers[i], true))) return rc;
+  const bool do_partial = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_PARTIAL)) != 0;
+  const bool do_reduce = (phases & (SOW_BWD_WEIGHTS | SOW_BWD_WEIGHTS_REDUCE)) != 0;
+  int rns[TNR_MAXI], rslab[TNR_MAXI];
+  const bool rows = (do_partial || do_reduce) && ((phases & SOW_BWD_GROUP_SLABS) || (do_partial && do_reduce)) &&
+                    group_rows_plan(layers, n, dtype, rns, rslab);
+  if (slabs_out)
+    for (int i = 0; i < n; ++i) {
+      const sow_layer_args& L = layers[i];
+      int ns = 0;
+      if (L.T > 0 && L.r_live <= 64)
+        ns = plan_ws(L.T, L.d_in, L.d_out, L.r_live, L.acc_kind == SOW_ACC_LOWRANK ? L.r_acc : 0, L.acc_kind, dtype).ns;
+      slabs_out[2 * i] = rows ? rns[2 * i] : ns;
+      slabs_out[2 * i + 1] = rows ? rns[2 * i + 1] : ns;
+    }
+  return rows ? 1 : 0;
+}
+
 int sow_backward_group_reduce_desc(const sow_layer_args* layers, int n, int dtype, int phases, void* descs_out, int* blocks_out) {
   if (!ok_dtype(dtype)) return SOW_ERR_DTYPE;
   if (n < 0) return SOW_ERR_SHAPE;

@@ -242,6 +242,15 @@ class LayerGroup:
         _launch(self.device, "sow_backward_group", _lib.load().sow_backward_group, self.arr, len(self.calls), self.dtype,
                 int(phases))
 
+    def weight_gradient_plan(self, phases: int = _lib.BWD_DATA | _lib.BWD_WEIGHTS):
+        """(row_owner_kernel: bool, [(slabs of x, slabs of dY) per layer]) for backward(phases) -- sow_backward_group_plan."""
+        n = len(self.calls)
+        slabs = (ctypes.c_int * (2 * n))()
+        rc = _lib.load().sow_backward_group_plan(self.arr, n, self.dtype, int(phases), slabs)
+        if rc < 0:
+            _lib.check(rc, "sow_backward_group_plan")
+        return bool(rc), [(slabs[2 * i], slabs[2 * i + 1]) for i in range(n)]
+
     def reduce_descs(self, phases: int):
         """Descriptors and block counts of the deferred weight-gradient reductions of this group (sow_reduce_batch), for a
         PARTIAL phase issued with the same `phases` flags (BWD_GROUP_SLABS included or not)."""

@@ -13,6 +13,7 @@ import json
 import os
 import types
 
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -481,6 +482,50 @@ def test_block_weight_gradients_row_owner_kernel(T):
     for c, (_, _, _, _, dA1, dB1, _) in zip(calls, ref):
         assert torch.equal(c._keep[7], dA1) and torch.equal(c._keep[8], dB1)
 
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_row_owner_kernel_random_groups(seed):
+    """Random groups that qualify for the row-owner kernel (checked through sow_backward_group_plan): widths that are not a
+    multiple of 64, more than 16 column groups (two column ranges), ranks 4 .. 64, ragged token counts, layers with bias --
+    dA, dB, dbias against float64 products of the operands the kernel reads."""
+    from sow_amd import _lib, ops
+    rng = np.random.default_rng(100 + seed)
+    widths = [72, 264, 512, 768, 1000, 1376, 2048, 2752]
+    for _attempt in range(20):
+        T = int(rng.choice([8200, 12000, 16392]))
+        n = int(rng.integers(5, 9))
+        specs = [(int(rng.choice(widths)), int(rng.choice(widths)), int(rng.choice([4, 8, 34, 50, 64])), bool(rng.integers(0, 2)))
+                 for _ in range(n)]
+        specs = [(di, do, r, hb and r < 64) for (di, do, r, hb) in specs]
+        gen = torch.Generator(device=DEV).manual_seed(seed)
+        calls = []
+        for (di, do, r, hb) in specs:
+            x = torch.randn(T, di, generator=gen, device=DEV).bfloat16()
+            dy = torch.randn(T, do, generator=gen, device=DEV).bfloat16()
+            A = (torch.randn(di, r, generator=gen, device=DEV) * 0.05).bfloat16()
+            B = (torch.randn(r, do, generator=gen, device=DEV) * 0.05).bfloat16()
+            bias = torch.zeros(do, device=DEV, dtype=torch.bfloat16) if hb else None
+            out = (torch.zeros_like(A), torch.zeros_like(B), torch.zeros_like(bias) if hb else None)
+            calls.append(ops.LayerCall(x, A, B, bias=bias, scale=1.5, dy2=dy, dx=torch.empty_like(x), out=out, grad_beta=0.0))
+        grp = ops.LayerGroup(calls)
+        rows, slabs = grp.weight_gradient_plan()
+        if rows:
+            break
+        del calls, grp
+        torch.cuda.empty_cache()
+    assert rows, "no qualifying group drawn"
+    grp.forward()
+    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    torch.cuda.synchronize()
+    for c, (di, do, r, hb) in zip(calls, specs):
+        x, A, B, dy = c._keep[0], c._keep[1], c._keep[2], c._keep[6]
+        h = c.h.view(-1, 64)[:, :r].double()
+        dh = (1.5 * (dy.double() @ B.double().t())).bfloat16().double()
+        assert rel_err(c._keep[7].double().cpu(), (x.double().t() @ dh).cpu()) < 8e-3, (T, di, do, r)
+        assert rel_err(c._keep[8].double().cpu(), (h.t() @ dy.double()).cpu()) < 8e-3, (T, di, do, r)
+        if hb:
+            assert rel_err(c._keep[9].double().cpu(), dy.double().sum(0).cpu()) < 8e-3
 
 
 # ---------------------------------------------------------------------------------------------

@@ -411,3 +411,44 @@ def test_attach_refuses_a_ddp_wrapped_model_and_optimizer_state_round_trips():
     assert torch.equal(other.exp_avg, opt.exp_avg) and torch.equal(other.exp_avg_sq, opt.exp_avg_sq)
     with pytest.raises(ValueError):
         FactorAdamW(FactorBucket([nn.Parameter(torch.zeros(5))])).load_state_dict(sd)
+
+
+def test_group_slab_plan_is_a_pure_function_of_the_layer_list():
+    """sow_backward_group_plan (host logic only, no launch): the seven projections of a llama_60m decoder block plan to one
+    resident round of equal-work blocks for the row-owner weight-gradient kernel (13 slabs for the 512-wide operands, 18 per
+    column range for the 1376-wide ones: 251 blocks); three q / k / v layers do not fill the chip and keep the single-layer
+    slab counts; a deferred reduction (PARTIAL alone) keeps them too unless SOW_BWD_GROUP_SLABS is passed; short inputs
+    (llama-7b fine-tuning, T = 1024) never qualify."""
+    from sow_amd import _lib
+    lib = _lib.load()
+
+    def layer(T, d_in, d_out, r=50):
+        ws = lib.sow_workspace_bytes(T, d_in, d_out, r, 0, 0, _lib.BF16)
+        fake = 1 << 20     # the plan looks at alignment and sizes only; nothing is dereferenced
+        return _lib.LayerArgs(x=fake, A=fake, B=fake, y=fake, h_save=fake, dy=fake, dx=fake, dA=fake, dB=fake, T=T, d_in=d_in,
+                              d_out=d_out, r_live=r, r_acc=0, acc_kind=0, scale=1.0, grad_beta=0.0, workspace=fake,
+                              workspace_bytes=ws + 256)
+
+    def plan(layers, phases):
+        arr = (_lib.LayerArgs * len(layers))(*layers)
+        slabs = (ctypes.c_int * (2 * len(layers)))()
+        return lib.sow_backward_group_plan(arr, len(layers), _lib.BF16, phases, slabs), list(slabs)
+
+    block = [layer(32768, 512, 512)] * 4 + [layer(32768, 512, 1376)] * 2 + [layer(32768, 1376, 512)]
+    full = _lib.BWD_DATA | _lib.BWD_WEIGHTS
+    rows, slabs = plan(block, full)
+    assert rows == 1 and slabs == [13] * 9 + [18, 13, 18, 18, 13]
+    assert sum(n * (2 if i in (9, 11, 12) else 1) for i, n in enumerate(slabs)) == 251
+    assert plan(block, _lib.BWD_WEIGHTS_PARTIAL) == (0, [32] * 8 + [16] * 6)
+    assert plan(block, _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS) == (1, slabs)
+    assert plan(block, _lib.BWD_WEIGHTS_REDUCE | _lib.BWD_GROUP_SLABS) == (1, slabs)
+    assert plan(block, _lib.BWD_DATA)[0] == 0
+    assert plan(block[:3], full) == (0, [32] * 6)
+    assert plan([layer(1024, 4096, 4096, 8)] * 3 + [layer(1024, 4096, 11008, 8), layer(1024, 11008, 4096, 8)], full)[0] == 0
+    # an unaligned input pointer or a workspace sized by an older rule: no row-owner kernel, never an error
+    odd = layer(32768, 512, 512)
+    odd.x = (1 << 20) + 8
+    assert plan(block[:6] + [odd], full)[0] == 0
+    small = layer(32768, 1376, 512)
+    small.workspace_bytes = 1 << 20
+    assert plan(block[:6] + [small], full)[0] == 0
