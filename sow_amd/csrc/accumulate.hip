@@ -6,7 +6,7 @@
 // latency-bound, so the batch entry point runs each PHASE once for all layers:
 //   1. acc_l = beta_l * acc_l + scale_l * A_l . B_l          one grid, (64 x 64 tile, layer) per workgroup
 //   2. panel copy-in, Householder panel + org2r, copy-out     one grid each, one workgroup per layer for the panel
-//      (the panel kernel is latency-bound on one CU: 0.1 - 0.55 ms; 56 - 160 of them now run side by side)
+//      (the panel kernel is latency-bound on one CU: 0.1 - 1.3 ms; 56 - 112 of them run side by side in ONE launch)
 //   3. B_l <- 0                                               one multi-tensor memset
 // A is overwritten IN PLACE by the new orthonormal factor after the update has consumed it (stream order), so the
 // caller's parameter storage -- and any flat bucket that views it -- stays where it is.
@@ -14,6 +14,8 @@
 #include "qr_panel.hpp"
 
 namespace sow {
+
+size_t qr_panel_lds_bytes(int m, int kc);   // qr.hip
 
 // ---------------------------------------------------------------------------------------------
 // 1. batched rank-r update (r <= 64), fp32 accumulation, one rounding.  HBM-bound on acc (1 read + 1 write).
@@ -81,11 +83,22 @@ template <typename Tin> __global__ void qr_copy_in_batch_kernel(const AccBatch b
   }
 }
 
-__global__ __launch_bounds__(1024) void qr_panel_batch_kernel(const AccBatch b) {
+// the panel kernel is latency-bound (0.5 - 1.3 ms per matrix on one CU) and needs four words per layer: its own compact
+// descriptor block lets ONE launch cover up to 112 layers (the slowest matrix sets the time, not the sum over launches)
+struct QrItem {
+  float* Pt;
+  float* Qt;
+  int m, kc, r_new, pad;
+};
+constexpr int QR_MAXB = 112;   // 112 x 32 bytes of kernel arguments
+struct QrBatch {
+  QrItem it[QR_MAXB];
+  int n;
+};
+__global__ __launch_bounds__(1024) void qr_panel_batch_kernel(const QrBatch b) {
   extern __shared__ __attribute__((aligned(16))) float qsm_b[];
-  const AccItem& it = b.it[blockIdx.x];
-  if (!it.draw) return;
-  qr_panel_body(it.Pt, it.Qt, it.d_in, it.kc, it.r_new, qsm_b);
+  const QrItem& it = b.it[blockIdx.x];
+  qr_panel_body(it.Pt, it.Qt, it.m, it.kc, it.r_new, qsm_b);
 }
 
 template <typename Tout> __global__ void qr_copy_out_batch_kernel(const AccBatch b) {
@@ -100,15 +113,14 @@ template <typename Tout> __global__ void qr_copy_out_batch_kernel(const AccBatch
   }
 }
 
-size_t qr_panel_lds_bytes(int m, int kc);   // qr.hip
-
 int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t stream) {
-  for (int base = 0; base < n; base += ACC_MAXB) {
-    AccBatch b{};
+  // phase-major over the whole list (stream order = dependency order): 1. rank-r updates and panel copy-in, 48 layers per
+  // launch; 2. the Householder panels, up to 112 layers per launch; 3. copy-out (new A, in place: every update has read
+  // the old A by then)
+  auto batch_of = [&](int base, AccBatch& b, int& max_tiles, int& max_m, bool& any_qr) {
+    b = AccBatch{};
     b.n = n - base < ACC_MAXB ? n - base : ACC_MAXB;
-    int max_tiles = 0, max_m = 0;
-    size_t max_lds = 0;
-    bool any_qr = false;
+    max_tiles = 0, max_m = 0, any_qr = false;
     for (int i = 0; i < b.n; ++i) {
       b.it[i] = items[base + i];
       const AccItem& it = b.it[i];
@@ -117,11 +129,16 @@ int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t 
       if (it.draw) {
         any_qr = true;
         if (it.d_in > max_m) max_m = it.d_in;
-        const size_t l = qr_panel_lds_bytes(it.d_in, it.kc);
-        if (l > max_lds) max_lds = l;
       }
     }
-    // 1. rank-r updates
+  };
+  for (int i = 0; i < n; ++i)
+    if (items[i].draw && qr_panel_lds_bytes(items[i].d_in, items[i].kc) > 150 * 1024) return SOW_ERR_UNSUPPORTED;
+  for (int base = 0; base < n; base += ACC_MAXB) {
+    AccBatch b;
+    int max_tiles, max_m;
+    bool any_qr;
+    batch_of(base, b, max_tiles, max_m, any_qr);
     const int gx = max_tiles < 64 ? max_tiles : 64;   // tile loop inside: keeps the grid at <= 64 x n workgroups
     if (dtype == SOW_F32)
       hipLaunchKernelGGL(rank_update_batch_kernel<float>, dim3(gx, b.n), dim3(256), 0, stream, b);
@@ -129,17 +146,43 @@ int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t 
       hipLaunchKernelGGL(rank_update_batch_kernel<bf16_t>, dim3(gx, b.n), dim3(256), 0, stream, b);
     SOW_CHECK_LAUNCH();
     if (!any_qr) continue;
-    // 2. new A = Q[:, :r_new] of the Gaussian draws
-    if (max_lds > 150 * 1024) return SOW_ERR_UNSUPPORTED;
     const int gc = (max_m * 64 + 255) / 256 < 64 ? (max_m * 64 + 255) / 256 : 64;
     if (dtype == SOW_F32)
       hipLaunchKernelGGL(qr_copy_in_batch_kernel<float>, dim3(gc, b.n), dim3(256), 0, stream, b);
     else
       hipLaunchKernelGGL(qr_copy_in_batch_kernel<bf16_t>, dim3(gc, b.n), dim3(256), 0, stream, b);
     SOW_CHECK_LAUNCH();
-    SOW_SET_MAX_LDS_ONCE(150 * 1024, qr_panel_batch_kernel);
-    hipLaunchKernelGGL(qr_panel_batch_kernel, dim3(b.n), dim3(1024), max_lds, stream, b);
+  }
+  {
+    QrBatch q{};
+    size_t max_lds = 0;
+    auto flush = [&]() {
+      if (q.n == 0) return;
+      SOW_SET_MAX_LDS_ONCE(150 * 1024, qr_panel_batch_kernel);
+      hipLaunchKernelGGL(qr_panel_batch_kernel, dim3(q.n), dim3(1024), max_lds, stream, q);
+      q.n = 0, max_lds = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      const AccItem& it = items[i];
+      if (!it.draw) continue;
+      q.it[q.n++] = QrItem{it.Pt, it.Qt, it.d_in, it.kc, it.r_new, 0};
+      const size_t l = qr_panel_lds_bytes(it.d_in, it.kc);
+      if (l > max_lds) max_lds = l;
+      if (q.n == QR_MAXB) {
+        flush();
+        SOW_CHECK_LAUNCH();
+      }
+    }
+    flush();
     SOW_CHECK_LAUNCH();
+  }
+  for (int base = 0; base < n; base += ACC_MAXB) {
+    AccBatch b;
+    int max_tiles, max_m;
+    bool any_qr;
+    batch_of(base, b, max_tiles, max_m, any_qr);
+    if (!any_qr) continue;
+    const int gc = (max_m * 64 + 255) / 256 < 64 ? (max_m * 64 + 255) / 256 : 64;
     if (dtype == SOW_F32)
       hipLaunchKernelGGL(qr_copy_out_batch_kernel<float>, dim3(gc, b.n), dim3(256), 0, stream, b);
     else
