@@ -42,6 +42,14 @@
 
 namespace sow {
 
+#ifdef C3_EXPERIMENT_CHEAP_FSPLIT   // timing experiment only (bf16-accurate results): what the per-use split of the FACTOR fragments costs
+__device__ __forceinline__ void fsplit3v(float x0, float x1, u32x4 (&pl)[3], int e) {
+  const uint32_t h = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, x0), 0x07060302u);
+  pl[0][e] = h, pl[1][e] = h, pl[2][e] = h;
+}
+#else
+#define fsplit3v split3v
+#endif
 constexpr int C3_NTG = 2;
 constexpr int C3_NCW = 2 * C3_NTG;
 constexpr int C3_NLW = 2;
@@ -235,10 +243,10 @@ template <bool BWD, bool X3> __global__ __launch_bounds__(C3_THREADS, 4) void ch
         split3v(xb[2], xb[3], xp, 3);
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-          split3v(fa[tl][0], fa[tl][1], fp[tl], 0);
-          split3v(fa[tl][2], fa[tl][3], fp[tl], 1);
-          split3v(fb[tl][0], fb[tl][1], fp[tl], 2);
-          split3v(fb[tl][2], fb[tl][3], fp[tl], 3);
+          fsplit3v(fa[tl][0], fa[tl][1], fp[tl], 0);
+          fsplit3v(fa[tl][2], fa[tl][3], fp[tl], 1);
+          fsplit3v(fb[tl][0], fb[tl][1], fp[tl], 2);
+          fsplit3v(fb[tl][2], fb[tl][3], fp[tl], 3);
         }
         hacc[0] = mfma_x3(fp[0], xp, hacc[0]);
         hacc[1] = mfma_x3(fp[1], xp, hacc[1]);
@@ -439,10 +447,10 @@ template <bool BWD, bool X3> __global__ __launch_bounds__(C3_THREADS, 4) void ch
           }
           LGKM_WAIT0();
           u32x4 f2p[3];
-          split3v(fa[0], fa[1], f2p, 0);
-          split3v(fa[2], fa[3], f2p, 1);
-          split3v(fb[0], fb[1], f2p, 2);
-          split3v(fb[2], fb[3], f2p, 3);
+          fsplit3v(fa[0], fa[1], f2p, 0);
+          fsplit3v(fa[2], fa[3], f2p, 1);
+          fsplit3v(fb[0], fb[1], f2p, 2);
+          fsplit3v(fb[2], fb[3], f2p, 3);
           yacc = mfma_x3(f2p, hp[s4], yacc);
         }
         if (sl > 0) flush_store(sl - 1, s4);
