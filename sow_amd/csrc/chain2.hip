@@ -5,7 +5,7 @@
 // kernel:
 //   * LDS-DMA (`global_load_lds_dwordx4`) for EVERYTHING that is read: X streams through per-token-group
 //     rings of [32 tok x 64 k] stages (no VGPR staging, counted s_waitcnt vmcnt); two loader waves
-//     stream the factors as 64-row chunks into a 4-slot LDS ring, 3 chunks ahead of the consumers.
+//     stream the factors as 64-row chunks into a 6-slot LDS ring, 5 chunks ahead of the consumers.
 //   * `ds_read_b64_tr_b16`: the factors stay in their storage layout (A is [d_in, r], B is [r, d_out]);
 //     in the forward direction both have the contraction index as their ROW index and are read
 //     transposed; in the backward direction both are k-contiguous and read with ds_read_b128 / b64.
@@ -26,7 +26,7 @@
 // in phase 2 each takes one 32-column tile of every 64-column slice and half of the store rows.
 // Workgroup = 64 tokens = 6 waves: compute waves 0-3 (token group = w & 1, half = w >> 1) and loader
 // waves 4-5; 80 KiB of LDS, two workgroups per CU (12 waves, 3 per SIMD).  One raw s_barrier per
-// chunk hands chunk c to the consumers and frees the slot of chunk c-1 for the loaders (chunk c+3).
+// chunk hands chunk c to the consumers and frees the slot of chunk c-1 for the loaders (chunk c+5).
 // All LDS reads of the compute waves are inline asm: for a compiler-visible LDS read hipcc emits
 // `s_waitcnt vmcnt(0)` while LDS-DMA is outstanding, which would drain the rings every step.
 //
@@ -72,14 +72,27 @@ constexpr int C2_NTG = 2;             // token groups (32 tokens) per workgroup
 constexpr int C2_NCW = 2 * C2_NTG;    // compute waves: (token group, half)
 constexpr int C2_NLW = 2;             // loader waves
 constexpr int C2_BM = 32 * C2_NTG;    // tokens per workgroup
-constexpr int C2_DEPTH = 6;           // X stage slots per token group (5 in flight)
+// Ring split of the 80 KiB (A/B builds: make VARIANT=... DEFS="-DC2_DEPTH_X=6 -DC2_NSLOT_X=4 -DC2_AHEAD_X=3"; slots + depth = 10).
+// The factor chunks come from L2, but under a saturated HBM stream an L2 hit takes ~2 us, and a late chunk stalls all six
+// waves at the stage barrier (tools/chain_stamps.py: the loader waves spend 1.2 us of a 14-us block waiting for their DMA;
+// with the factor DMA compiled out the kernel is 12 % faster).  Round 2 moved two X slots to the factor ring: 4 X slots
+// (3 in flight) + 6 chunk slots (5 ahead) against 6 + 4 (3 ahead): step 3.92 -> 3.84 ms on one box (5 + 5: 3.87);
+// q + k + v forward 52.7 -> 50.1 us, the K = 1376 forward 34.9 -> 35.8 us.
+#ifndef C2_DEPTH_X
+#define C2_DEPTH_X 4
+#define C2_NSLOT_X 6
+#define C2_AHEAD_X 5
+#endif
+constexpr int C2_DEPTH = C2_DEPTH_X;   // X stage slots per token group (DEPTH - 1 in flight)
 constexpr int C2_STAGE = 4096;        // [32 tok][64 k] bf16
-constexpr int C2_NSLOT = 4;           // factor chunk slots
-constexpr int C2_AHEAD = 3;           // chunks the loaders run ahead: the slot of chunk c+3 held chunk c-1, drained before barrier c (2 ahead: +2.7 % step time; 5 slots / 4 ahead with a 5-deep X ring: +1 %)
+constexpr int C2_NSLOT = C2_NSLOT_X;   // factor chunk slots
+constexpr int C2_AHEAD = C2_AHEAD_X;   // chunks the loaders run ahead: the slot of chunk c + AHEAD held chunk c - 1, drained before barrier c
+static_assert(C2_NSLOT == C2_AHEAD + 1 && C2_NSLOT + C2_DEPTH == 10 && C2_DEPTH >= 4 && C2_DEPTH <= 6,
+              "80 KiB: 8 KiB per chunk slot + 2 x 4 KiB per X slot; the 32-KiB hand-off exchange must fit behind the chunk ring");
 constexpr int C2_FSLOT = 8192;        // [64][64] bf16
 constexpr int C2_LPW = 8 / C2_NLW;    // 1-KiB DMA instructions per loader wave per chunk
 constexpr int C2_RING0 = C2_NSLOT * C2_FSLOT;
-constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 24 KiB per token group
+constexpr int C2_RING = C2_DEPTH * C2_STAGE;  // 16 KiB per token group
 constexpr int C2_LDS = C2_RING0 + C2_NTG * C2_RING;   // 80 KiB: two workgroups per CU
 constexpr int C2_THREADS = 64 * (C2_NCW + C2_NLW);
 constexpr int C2_RESIDENT = 512;      // resident workgroups of a persistent grid (2 per CU x 256 CUs)
@@ -155,6 +168,9 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     auto issue = [&](int c) {
 #ifdef C2_EXPERIMENT_NO_FACTOR_DMA   // timing experiment only (wrong results): what the factor re-reads from L2 cost
       if (c >= C2_NSLOT) return;
+#endif
+#ifdef C2_EXPERIMENT_HALF_FACTOR_DMA   // timing experiment only (wrong results): every other block re-uses stale chunks
+      if (bid & 1) return;
 #endif
       char* slot = smem + (c % C2_NSLOT) * C2_FSLOT;
       const int ci = c < nst ? st0 + c : sl0 + (c - nst);   // chunk index inside its matrix
@@ -447,7 +463,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   auto tile_addr = [&](int buf, int row, int chunk) {   // chunk = 16-byte (4 fp32) index 0..15
     return ring_a + (uint32_t)(buf * 8192 + row * 256 + ((chunk ^ (row & 15)) * 16));
   };
-  const bool pairf = p.pair_flush != 0;   // park tiles rotate through 3 buffers and two slices are stored at a time
+  const bool pairf = p.pair_flush != 0 && C2_RING >= 3 * 8192;   // park tiles rotate through 3 buffers and two slices are stored at a time
   auto flush = [&](int sl_prev) {   // store rows 16*hh .. 16*hh+15 of slice sl_prev from its park tile
     const int buf = pairf ? sl_prev % 3 : (sl_prev & 1);
     u32x4 v0[2], v1[2];
@@ -543,7 +559,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   // epilogue, one ds_read_b128 per 16-byte store, and ring slots 0..2 stay free during phase 2
   constexpr bool park16 = P16;   // host-selected instantiation: every layer of the launch has pair_flush, beta = 0 and no bias
   auto tile16_addr = [&](int buf, int row, int chunk) {   // chunk = 16-byte (8 bf16) index 0..7
-    return ring_a + (uint32_t)(3 * C2_STAGE + buf * 4096 + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16));
+    return ring_a + (uint32_t)((C2_DEPTH - 3) * C2_STAGE + buf * 4096 + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16));
   };
   auto store16 = [&](int r, int col, u32x4 ov) {
     const int64_t tk = tok0 + r;
@@ -609,7 +625,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const u32x2 v = {pack_bf16x2(yacc[4 * rq + 0], yacc[4 * rq + 1]), pack_bf16x2(yacc[4 * rq + 2], yacc[4 * rq + 3])};
-        *(u32x2*)(ring + 3 * C2_STAGE + (sl % 3) * 4096 + li * 128 + (((hh * 4 + rq) ^ ((li >> 1) & 7)) * 16) + lh * 8) = v;
+        *(u32x2*)(ring + (C2_DEPTH - 3) * C2_STAGE + (sl % 3) * 4096 + li * 128 + (((hh * 4 + rq) ^ ((li >> 1) & 7)) * 16) + lh * 8) = v;
       }
     } else {
     if (pairf) {
