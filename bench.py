@@ -108,7 +108,9 @@ class Stack:
             g.manual_seed(1234 + li)
             self.x.append(torch.randn(T, d_in, generator=g, device=device, dtype=torch.float32).to(dtype))
             self.dy.append(torch.randn(T, d_out, generator=g, device=device, dtype=torch.float32).to(dtype))
-            a = torch.linalg.qr(torch.randn(d_in, r, generator=g, device=device) * 0.02)[0]  # orthonormal columns
+            # orthonormal columns; factored on the host: the GPU QR is ~300 tiny rocsolver launches per layer, which a
+            # counter-collecting profiler run (rocprofv3 --pmc) spends minutes on before the first kernel of interest
+            a = torch.linalg.qr(torch.randn(d_in, r, generator=g, device=device).cpu() * 0.02)[0].to(device)
             b = torch.randn(r, d_out, generator=g, device=device) * 0.02
             self.A.append(torch.nn.Parameter(a.to(dtype).contiguous()))
             self.B.append(torch.nn.Parameter(b.to(dtype).contiguous()))
