@@ -208,10 +208,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
           *(uint32_t*)(smem + (c % C2_NSLOT) * C2_FSLOT + lr * 128 + img_chunk<TR>(lr, cc) * 16 + (lane & 3) * 4) = last_row_dw;
         }
       }
-      if (c == nst) {      // the two hand-off barriers of the compute waves (partial-H exchange)
-        raw_barrier();
-        raw_barrier();
-      }
+      if (c == nst) raw_barrier();   // the hand-off barrier of the compute waves (exchange of the rank tiles)
       const uint64_t tk1 = C2_TICK();
       raw_barrier();   // chunk c visible to the consumers; they have finished chunk c-1
       C2_ACC(tw_bar, tk1);
@@ -221,8 +218,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     C2_PUT(w == C2_NCW, 9, tw_bar);
     if (nsl > 0) {
       raw_barrier();   // matches the compute waves' final "last slice parked" barrier
-    } else {           // H-only call (D2 == 0): the hand-off barriers were not met inside the loop
-      raw_barrier();
+    } else {           // H-only call (D2 == 0): the hand-off barrier was not met inside the loop
       raw_barrier();
     }
     raw_barrier();     // end of block: the compute waves have read the last parked slice out of the rings
@@ -287,16 +283,13 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   const int xsw = (li >> 1) & 7;                // b128 row swizzle
   //   phase 1 (natural k):  TR rows 16ks + 8h + q (+4)      | B128 chunk 2ks + h of row (tile*32 + li)
   //   phase 2 (permuted k): TR rows 16ks + 4h + q (+8)      | two B64 at k = 16ks + 4h and 16ks + 8 + 4h
-  uint32_t foff1[2], foff2;
-#pragma unroll
-  for (int tl = 0; tl < 2; ++tl) {
-    if constexpr (TR) {
-      const int col = tl * 32 + 16 * (g & 1) + 4 * pp;
-      const int r1 = 8 * h2 + q;
-      foff1[tl] = (uint32_t)(r1 * 128 + img_chunk<true>(r1, col >> 3) * 16 + (col & 7) * 2);
-    } else {
-      foff1[tl] = (uint32_t)((tl * 32 + li) * 128);
-    }
+  uint32_t foff1[1], foff2;   // phase 1: rank tile hh of the chunk image
+  if constexpr (TR) {
+    const int col = hh * 32 + 16 * (g & 1) + 4 * pp;
+    const int r1 = 8 * h2 + q;
+    foff1[0] = (uint32_t)(r1 * 128 + img_chunk<true>(r1, col >> 3) * 16 + (col & 7) * 2);
+  } else {
+    foff1[0] = (uint32_t)((hh * 32 + li) * 128);
   }
   if constexpr (TR) {
     const int col = hh * 32 + 16 * (g & 1) + 4 * pp;
@@ -306,11 +299,9 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     foff2 = (uint32_t)((hh * 32 + li) * 128 + 8 * lh);
   }
 
-  f32x16 hacc[2];   // H^T tiles (partial over this wave's K half): lane = token, registers = rank rows of tile rt
+  f32x16 hacc;   // H^T tile hh (ranks 32 hh .. 32 hh + 31) over the whole K range: lane = token, registers = rank rows
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) hacc[a][i] = 0.f;
+  for (int i = 0; i < 16; ++i) hacc[i] = 0.f;
 
   // stage s+DEPTH-1 is issued after barrier(s): by then BOTH waves of the token group are done with stage s-1
   const int pre = nst < (C2_DEPTH - 1) ? nst : (C2_DEPTH - 1);
@@ -332,52 +323,45 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
     if (st + C2_DEPTH - 1 < nst) issue_x(st + C2_DEPTH - 1);   // into the slot of stage st-1
     const uint32_t xs = ring_a + (uint32_t)((st % C2_DEPTH) * C2_STAGE) + xoff;
     const uint32_t fs = slot_a + (uint32_t)((st % C2_NSLOT) * C2_FSLOT);
-    u32x4 xf[2], ff[2][2];
-    DS_READ_B128(xf[0], xs + (uint32_t)(((4 * hh + 0 + lh) ^ xsw) * 16), 0);
-    DS_READ_B128(xf[1], xs + (uint32_t)(((4 * hh + 2 + lh) ^ xsw) * 16), 0);
+    // the two waves of a token group split the RANKS (tile hh each), not K: every wave contracts the whole stage, so its
+    // accumulator is final and the hand-off is an exchange of 2 KiB of bf16 instead of a sum of 8 KiB of fp32 partials
+    u32x4 xf[4], ff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) DS_READ_B128(xf[ks], xs + (uint32_t)(((2 * ks + lh) ^ xsw) * 16), 0);
     if constexpr (TR) {
-      u32x2 bl[2][2], bh[2][2];
-      const uint32_t b0 = fs + foff1[0] + (uint32_t)(hh * 4096), b1 = fs + foff1[1] + (uint32_t)(hh * 4096);
-      DS_READ_TR(bl[0][0], b0, 0);
-      DS_READ_TR(bh[0][0], b0, 512);
-      DS_READ_TR(bl[0][1], b1, 0);
-      DS_READ_TR(bh[0][1], b1, 512);
-      DS_READ_TR(bl[1][0], b0, 2048);
-      DS_READ_TR(bh[1][0], b0, 2048 + 512);
-      DS_READ_TR(bl[1][1], b1, 2048);
-      DS_READ_TR(bh[1][1], b1, 2048 + 512);
+      u32x2 bl[4], bh[4];
+      const uint32_t b0 = fs + foff1[0];
+      DS_READ_TR(bl[0], b0, 0);
+      DS_READ_TR(bh[0], b0, 512);
+      DS_READ_TR(bl[1], b0, 2048);
+      DS_READ_TR(bh[1], b0, 2048 + 512);
+      DS_READ_TR(bl[2], b0, 4096);
+      DS_READ_TR(bh[2], b0, 4096 + 512);
+      DS_READ_TR(bl[3], b0, 6144);
+      DS_READ_TR(bh[3], b0, 6144 + 512);
       LGKM_WAIT0();
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) ff[kk][tl] = join2(bl[kk][tl], bh[kk][tl]);
+      for (int ks = 0; ks < 4; ++ks) ff[ks] = join2(bl[ks], bh[ks]);
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint32_t o = (uint32_t)(((4 * hh + 2 * kk + lh) ^ xsw) * 16);
-        DS_READ_B128(ff[kk][0], fs + foff1[0] + o, 0);
-        DS_READ_B128(ff[kk][1], fs + foff1[1] + o, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) DS_READ_B128(ff[ks], fs + foff1[0] + (uint32_t)(((2 * ks + lh) ^ xsw) * 16), 0);
       LGKM_WAIT0();
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      hacc[0] = mfma32(as_bf16x8(ff[kk][0]), as_bf16x8(xf[kk]), hacc[0]);
-      hacc[1] = mfma32(as_bf16x8(ff[kk][1]), as_bf16x8(xf[kk]), hacc[1]);
-    }
+    for (int ks = 0; ks < 4; ++ks) hacc = mfma32(as_bf16x8(ff[ks]), as_bf16x8(xf[ks]), hacc);
     __builtin_amdgcn_sched_barrier(0);
   }
 
   C2_STAMP(2);
-  // ================================================================== hand-off: sum the two K halves
-  // barrier H0: every X read of the workgroup is done, so the rings can hold the exchange buffers
-  // (fp32 [wave][tile][reg][lane], 8 KiB per wave); barrier H1: partials visible to the partner.
+  // ================================================================== hand-off: exchange the two rank tiles
+  // Each wave scales, masks and rounds its own 32 ranks (k-steps 2 hh, 2 hh + 1 of phase 2), parks them in the X slot that
+  // follows the last stage (free: the partner can only still be reading the slot of stage nst - 1), and after ONE barrier
+  // reads the partner's two k-steps.
   u32x4 hf[4];
   const int64_t tok = tok0 + li;
   if (p.Hload) {
     // phase-2-only workgroup: H comes from memory.  hf[s] of lane (li, lh) = ranks 16s + 4lh + (0..3) and
     // 16s + 8 + 4lh + (0..3) of token li; the 1.0 of column 63 (dbias trick) must not reach the product.
-    raw_barrier();
     raw_barrier();
     const bf16_t* Hl = (const bf16_t*)p.Hload + tok * 64 + 4 * lh;
 #pragma unroll
@@ -391,65 +375,49 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
       hf[s4] = join2(lo, hi);
     }
   } else {
-  raw_barrier();
-  {
-    float* xch = (float*)(smem + C2_RING0) + w * 2048;
+    u32x4 own[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (p.Hpartial) {
+      // phase-1 slab of a short-T split: the raw fp32 sums of this K range, one 32-rank tile per wave
+      if (tok < p.M) {
+        float* Hp = p.Hpartial + ((int64_t)split * p.M + tok) * 64 + hh * 32 + 4 * lh;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rq = 0; rq < 4; ++rq)
+          *(f32x4*)(Hp + 8 * rq) = (f32x4){hacc[4 * rq + 0], hacc[4 * rq + 1], hacc[4 * rq + 2], hacc[4 * rq + 3]};
+      }
+    } else {
+      // scale, mask rank rows >= r (overlap garbage / zeros), round to bf16; the saved copy [M, 64] (scaled live columns,
+      // zeros, and 1.0 in column 63 when free -- the dbias trick of the skinny-TN kernel) is written as 8-byte row pieces
+      float hv[16];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) xch[(rt * 16 + reg) * 64 + lane] = hacc[rt][reg];
-  }
-  raw_barrier();
-  {
-    const uint32_t pa = lds_addr(smem + C2_RING0) + (uint32_t)((w ^ 2) * 8192 + lane * 4);
-    uint32_t pv[32];
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r = hh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        hv[reg] = r < rb ? hacc[reg] * p.scale : 0.f;
+      }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) DS_READ_B32(pv[i], pa, i * 256);
-    LGKM_WAIT0();
+      for (int a = 0; a < 2; ++a)
+        own[a] = (u32x4){pack_bf16x2(hv[8 * a + 0], hv[8 * a + 1]), pack_bf16x2(hv[8 * a + 2], hv[8 * a + 3]),
+                         pack_bf16x2(hv[8 * a + 4], hv[8 * a + 5]), pack_bf16x2(hv[8 * a + 6], hv[8 * a + 7])};
+      if (p.Hsave && tok < p.M) {
+        bf16_t* Hs = (bf16_t*)p.Hsave + tok * 64 + hh * 32 + 4 * lh;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) hacc[rt][reg] += __builtin_bit_cast(float, pv[rt * 16 + reg]);
-  }
-  if (p.Hpartial) {
-    // phase-1 slab of a short-T split: the raw fp32 sums of this K range, one 32-rank tile per half
-    if (tok < p.M) {
-      float* Hp = p.Hpartial + ((int64_t)split * p.M + tok) * 64 + hh * 32 + 4 * lh;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq)
-        *(f32x4*)(Hp + 8 * rq) = hh ? (f32x4){hacc[1][4 * rq + 0], hacc[1][4 * rq + 1], hacc[1][4 * rq + 2], hacc[1][4 * rq + 3]}
-                                    : (f32x4){hacc[0][4 * rq + 0], hacc[0][4 * rq + 1], hacc[0][4 * rq + 2], hacc[0][4 * rq + 3]};
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) hf[s4] = (u32x4){0u, 0u, 0u, 0u};
-  } else {
-  // scale, mask rank rows >= r (overlap garbage / zeros), round to bf16: hf[s] is the phase-2 B operand
-  // of k-step s; the saved copy [M, 64] (scaled live columns, zeros, and 1.0 in column 63 when free --
-  // the dbias trick of the skinny-TN kernel) is written as 8-byte row pieces, one 32-column tile per half.
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    float hv[16];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-      hv[reg] = r < rb ? hacc[rt][reg] * p.scale : 0.f;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-      hf[2 * rt + a] = (u32x4){pack_bf16x2(hv[8 * a + 0], hv[8 * a + 1]), pack_bf16x2(hv[8 * a + 2], hv[8 * a + 3]),
-                               pack_bf16x2(hv[8 * a + 4], hv[8 * a + 5]), pack_bf16x2(hv[8 * a + 6], hv[8 * a + 7])};
-    if (p.Hsave && hh == rt && tok < p.M) {
-      bf16_t* Hs = (bf16_t*)p.Hsave + tok * 64 + rt * 32 + 4 * lh;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        u32x2 v = {pack_bf16x2(hv[4 * rq + 0], hv[4 * rq + 1]), pack_bf16x2(hv[4 * rq + 2], hv[4 * rq + 3])};
-        if (rt == 1 && rq == 3 && lh == 1 && rb < 64) v[1] = (v[1] & 0xffffu) | 0x3F800000u;  // column 63 <- 1.0
-        *(u32x2*)(Hs + 8 * rq) = v;
+        for (int rq = 0; rq < 4; ++rq) {
+          u32x2 v = {pack_bf16x2(hv[4 * rq + 0], hv[4 * rq + 1]), pack_bf16x2(hv[4 * rq + 2], hv[4 * rq + 3])};
+          if (hh == 1 && rq == 3 && lh == 1 && rb < 64) v[1] = (v[1] & 0xffffu) | 0x3F800000u;  // column 63 <- 1.0
+          *(u32x2*)(Hs + 8 * rq) = v;
+        }
       }
     }
-  }
-  }
-
+    char* xch = ring + (nst % C2_DEPTH) * C2_STAGE;   // [half][k-step][lane] x 16 bytes
+    *(u32x4*)(xch + hh * 2048 + lane * 16) = own[0];
+    *(u32x4*)(xch + hh * 2048 + 1024 + lane * 16) = own[1];
+    raw_barrier();   // both rank tiles of the token group are parked
+    u32x4 oth[2];
+    const uint32_t pa = ring_a + (uint32_t)((nst % C2_DEPTH) * C2_STAGE + (hh ^ 1) * 2048 + lane * 16);
+    DS_READ_B128(oth[0], pa, 0);
+    DS_READ_B128(oth[1], pa, 1024);
+    LGKM_WAIT0();
+    hf[0] = hh ? oth[0] : own[0], hf[1] = hh ? oth[1] : own[1];   // (hh is wave-uniform; no dynamic register indexing)
+    hf[2] = hh ? own[0] : oth[0], hf[3] = hh ? own[1] : oth[1];
   }
   C2_STAMP(3);
   // ================================================================== phase 2: Y^T = F2^T . H^T (column tile hh)

@@ -594,11 +594,13 @@ def test_accumulate_llama60m_unhooked_draws_are_orthonormal_and_fast():
         m.virtual_rank = min(m.in_features, m.out_features)
     accumulate(net)
     accumulate(net)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    accumulate(net)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3
+    ms = float("inf")
+    for _ in range(3):                 # best of three: a wall-clock bound on a shared box
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        accumulate(net)
+        torch.cuda.synchronize()
+        ms = min(ms, (time.perf_counter() - t0) * 1e3)
     for m in (net[0], net[4], net[6], net[55]):
         q = m.downscale_weights[0].data.double()
         assert float((q.t() @ q - torch.eye(50, device=DEV, dtype=torch.float64)).abs().max()) < 2e-2
