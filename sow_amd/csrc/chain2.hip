@@ -22,7 +22,8 @@
 // Measured with in-kernel stamps: a wave that does everything for its 32 tokens is bound by its own
 // instruction issue (each LDS-DMA / global store occupies the issuing wave ~100-180 cycles), not by HBM.
 // The work of one 32-token group is therefore split over TWO compute waves: in phase 1 each takes
-// half of every stage's DMA rows and half of its K range (two partial H^T, summed through LDS once);
+// half of every stage's DMA rows and one 32-rank tile of H^T over the whole K range (final accumulators; the two tiles
+// are exchanged as bf16 through LDS at the hand-off);
 // in phase 2 each takes one 32-column tile of every 64-column slice and half of the store rows.
 // Workgroup = 64 tokens = 6 waves: compute waves 0-3 (token group = w & 1, half = w >> 1) and loader
 // waves 4-5; 80 KiB of LDS, two workgroups per CU (12 waves, 3 per SIMD).  One raw s_barrier per
@@ -87,8 +88,12 @@ constexpr int C2_DEPTH = C2_DEPTH_X;   // X stage slots per token group (DEPTH -
 constexpr int C2_STAGE = 4096;        // [32 tok][64 k] bf16
 constexpr int C2_NSLOT = C2_NSLOT_X;   // factor chunk slots
 constexpr int C2_AHEAD = C2_AHEAD_X;   // chunks the loaders run ahead: the slot of chunk c + AHEAD held chunk c - 1, drained before barrier c
+#ifdef C2_EXPERIMENT_SHALLOW_X   // timing experiment: 3 X slots hold the bf16 park tiles but not the fp32 ones (bias / beta launches break)
+static_assert(C2_NSLOT == C2_AHEAD + 1 && C2_NSLOT + C2_DEPTH == 10 && C2_DEPTH >= 3 && C2_DEPTH <= 6, "80 KiB");
+#else
 static_assert(C2_NSLOT == C2_AHEAD + 1 && C2_NSLOT + C2_DEPTH == 10 && C2_DEPTH >= 4 && C2_DEPTH <= 6,
-              "80 KiB: 8 KiB per chunk slot + 2 x 4 KiB per X slot; the 32-KiB hand-off exchange must fit behind the chunk ring");
+              "80 KiB: 8 KiB per chunk slot + 2 x 4 KiB per X slot; two 8-KiB fp32 park tiles per token group must fit its X ring");
+#endif
 constexpr int C2_FSLOT = 8192;        // [64][64] bf16
 constexpr int C2_LPW = 8 / C2_NLW;    // 1-KiB DMA instructions per loader wave per chunk
 constexpr int C2_RING0 = C2_NSLOT * C2_FSLOT;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
       }
     }
   }
-  const int tg = w & 1, hh = w >> 1;   // token group, half (K half in phase 1, column tile in phase 2)
+  const int tg = w & 1, hh = w >> 1;   // token group, half (rank tile in phase 1, column tile in phase 2)
   const int li = lane & 31, lh = lane >> 5;
   const int g = lane >> 4, jj = lane & 15, q = jj >> 2, pp = jj & 3;  // transposed-read geometry
   const int h2 = g >> 1;
@@ -307,7 +312,7 @@ __device__ __forceinline__ void chain2_block(const ChainParams& p, const int bid
   const int pre = nst < (C2_DEPTH - 1) ? nst : (C2_DEPTH - 1);
   for (int st = 0; st < pre; ++st) issue_x(st);
 
-  // ================================================================== phase 1: H^T = F1^T . X^T (K half hh)
+  // ================================================================== phase 1: H^T = F1^T . X^T (rank tile hh)
   uint64_t tw_x = 0, tw_b1 = 0, tw_b2 = 0;
 #pragma unroll 1
   for (int st = 0; st < nst; ++st) {
