@@ -62,53 +62,59 @@ class TensorTrain:
         tensor = matrix.reshape((mm,) * order + (nn_,) * order)
         return TensorTrain.from_tensor(tensor, ranks).to(matrix.device)
 
+    # ------------------------------------------------------------------ constant trains and container plumbing
+    # (behaviour of reference tt.py:68-109: same names and results -- `clone` shares the core tensors, `to` moves them in
+    # place through `.data`, `type` rebinds them -- expressed through two private helpers)
+    def _core_shapes(self):
+        return [(self.ranks[k], self.input_shape[k], self.output_shape[k], self.ranks[k + 1]) for k in range(self.order)]
+
+    def _sibling(self, cores):
+        """A new train with this one's ranks / shapes around `cores`."""
+        other = TensorTrain(list(self.ranks), self.input_shape, self.output_shape)
+        other.cores = cores
+        return other
+
+    @classmethod
+    def _constant(cls, fill, ranks, input_shape, output_shape, device):
+        tt = cls(ranks, input_shape, output_shape)
+        tt.cores = [fill(shape) for shape in tt._core_shapes()]
+        return tt.to(device)
+
     @staticmethod
     def zeros(ranks, input_shape, output_shape, device="cpu"):
-        tt = TensorTrain(ranks, input_shape, output_shape)
-        tt.cores = [torch.zeros((ranks[i], input_shape[i], output_shape[i], ranks[i + 1])) for i in range(tt.order)]
-        tt.to(device)
-        return tt
+        return TensorTrain._constant(torch.zeros, ranks, input_shape, output_shape, device)
 
     @staticmethod
     def ones(ranks, input_shape, output_shape, device="cpu"):
-        tt = TensorTrain(ranks, input_shape, output_shape)
-        tt.cores = [torch.ones((ranks[i], input_shape[i], output_shape[i], ranks[i + 1])) for i in range(tt.order)]
-        tt.to(device)
-        return tt
+        return TensorTrain._constant(torch.ones, ranks, input_shape, output_shape, device)
 
-    # ------------------------------------------------------------------ housekeeping (tt.py:86-109)
     def numel(self):
-        return sum(core.numel() for core in self.cores)
+        return sum(int(c.numel()) for c in self.cores)
+
+    def size(self):
+        return [c.size() for c in self.cores]
 
     def to(self, device):
         self.device = device
-        if device is None or self.cores[0].device == torch.device(device):
-            return self
-        for core in self.cores:
-            core.data = core.data.to(device)
+        if device is not None and self.cores[0].device != torch.device(device):
+            for c in self.cores:
+                c.data = c.data.to(device)           # in place: views and optimizer references stay valid
         return self
 
     def clone(self):
-        tt = TensorTrain(list(self.ranks), self.input_shape, self.output_shape)
-        tt.cores = self.cores.copy()  # shallow, as the reference (tt.py:96-99)
-        return tt
+        return self._sibling(list(self.cores))       # shallow on purpose (reference tt.py:96-99)
 
     def detach(self):
-        tt = TensorTrain(list(self.ranks), self.input_shape, self.output_shape)
-        tt.cores = [core.detach() for core in self.cores]
-        return tt
+        return self._sibling([c.detach() for c in self.cores])
 
     def type(self, dtype):
-        self.cores = [core.type(dtype) for core in self.cores]
+        self.cores = [c.type(dtype) for c in self.cores]
         return self
 
     def requires_grad_(self, flag):
-        for core in self.cores:
-            core.requires_grad_(flag)
+        for c in self.cores:
+            c.requires_grad_(flag)
         return self
-
-    def size(self):
-        return [core.size() for core in self.cores]
 
     # ------------------------------------------------------------------ decomposition (tt.py:111-140)
     def decompose(self, tensor: torch.Tensor):
