@@ -136,6 +136,7 @@ enum Switch : int {
   SW_NO_PAIR_FLUSH,       // chain kernel stores one 64-column slice per flush (128-byte pieces) instead of two
   SW_F32_EXACT,           // fp32 kernels on the exact v_mfma_f32_32x32x2_f32 instead of the 3 x bf16 split
   SW_NO_PARK16,           // chain kernel parks output slices as fp32 even when bf16 would be exact
+  SW_TN_NO_NT_LOAD,       // row-owner weight-gradient kernel streams x / dY with plain (cached) loads
   SW_NO_TN_ROWS,          // grouped weight-gradient launches never use the row-owner kernel (group-planned slabs)
   SW_COUNT
 };

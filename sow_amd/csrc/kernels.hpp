@@ -114,6 +114,7 @@ constexpr int TNR_MAXI = 2 * TN_MAXG;
 struct TnRowsGroup {
   TnRowsItem it[TNR_MAXI];
   int n, total;
+  int nt_load;   // stream M with the non-temporal hint
 };
 constexpr int TNR_MAX_SLABS = 40;   // workspace capacity per operand (api.hip: plan_ws)
 // n items (T[i] tokens x D[i] columns, at most cap[i] slabs): slab counts such that the blocks of the group fill one

@@ -589,7 +589,7 @@ __device__ __forceinline__ void tnr_wait(int n) {   // all but the n most recent
 }
 
 template <int CGW>
-__device__ __forceinline__ void tnr_block(const TnRowsItem& J, const int b, char* smem, const int lane, const int w) {
+__device__ __forceinline__ void tnr_block(const TnRowsItem& J, const int b, char* smem, const int lane, const int w, const bool nt) {
   constexpr int KS = 2 / CGW;      // 16-token k-steps per stage
   constexpr int TOKS = 16 * KS;
   const int range = b % J.nr, slab = b / J.nr;
@@ -650,7 +650,8 @@ __device__ __forceinline__ void tnr_block(const TnRowsItem& J, const int b, char
         for (int hf = 0; hf < 2; ++hf) {
           const void* src = mp[im][hf];
           if (!whole && tt0 + mtok[im][hf] >= t_end) src = zp;
-          dma16(src, ms + (im * 2 + hf) * 1024);
+          if (nt) dma16_nt(src, ms + (im * 2 + hf) * 1024);
+          else dma16(src, ms + (im * 2 + hf) * 1024);
           mp[im][hf] += mstep[im][hf];
         }
       }
@@ -758,8 +759,8 @@ __global__ __launch_bounds__(64 * TNR_WAVES, 1) void tn_partial_rows_kernel(cons
       if (i < grp.n && blk >= grp.it[i].start) item = i;
     int tt = (int)threadIdx.x;
     asm volatile("" : "+v"(tt));   // keeps per-lane address arithmetic inside the iteration (see chain2.hip)
-    if (grp.it[item].cgw == 2) tnr_block<2>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w);
-    else tnr_block<1>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w);
+    if (grp.it[item].cgw == 2) tnr_block<2>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w, grp.nt_load != 0);
+    else tnr_block<1>(grp.it[item], blk - grp.it[item].start, smem, tt & 63, w, grp.nt_load != 0);
   }
 }
 
@@ -1347,6 +1348,9 @@ int launch_tn_rows(TnRowsItem* items, int n, hipStream_t stream) {
     g.it[i] = it;
   }
   g.total = total;
+  // M (x, dY) is streamed once: non-temporal loads keep it out of the Infinity Cache, where dh, the slab partials and the next
+  // kernels' operands live (the launch itself 135 -> 138 us, the step 3.82 -> 3.78 ms; TN_NO_NT_LOAD switch)
+  g.nt_load = sw_on(SW_TN_NO_NT_LOAD) ? 0 : 1;
   SOW_SET_MAX_LDS_ONCE(TNR_LDS, tn_partial_rows_kernel);
   hipLaunchKernelGGL(tn_partial_rows_kernel, dim3((unsigned)(total < 256 ? total : 256)), dim3(64 * TNR_WAVES), TNR_LDS, stream, g);
   SOW_CHECK_LAUNCH();
