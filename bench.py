@@ -75,9 +75,10 @@ def parse():
     ap.add_argument("--no-group-siblings", action="store_true",
                     help="--mode train: do NOT group q/k/v and gate/up (sow_amd.group_siblings: one autograd node and one grid per "
                          "kernel for the siblings of a decoder block)")
-    ap.add_argument("--reduce", choices=["batch", "layer"], default="batch",
+    ap.add_argument("--reduce", choices=["batch", "block", "layer"], default="batch",
                     help="weight-gradient reduction: one 5-us launch per layer, or deferred and batched into one launch at the end "
-                         "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients)")
+                         "of backward (sow_reduce_batch: same arithmetic, bit-identical gradients), or one batched launch per "
+                         "decoder block right after its partial sums")
     ap.add_argument("--tn-group", choices=["block", "group"], default="block",
                     help="weight-gradient partial sums: one launch per decoder block (7 layers, after the block's data-gradient "
                          "kernels) or one per launch group, right after that group's data-gradient kernel (dY still in the "
@@ -98,7 +99,9 @@ class Stack:
         from sow_amd import ops
         from sow_amd.dp import FactorBucket
         self.shapes, self.T, self.r, self.dtype, self.acc = shapes, T, r, dtype, acc
-        self.deferred = ops.DeferredReduce() if reduce == "batch" else None
+        self.deferred = ops.DeferredReduce() if reduce in ("batch", "block") else None
+        # "block": one batched reduction per decoder block, right after its partial sums (they are still in the Infinity Cache)
+        self.block_reduce = [ops.DeferredReduce() for _ in range(len(shapes) // len(BLOCK_NAMES))] if reduce == "block" else None
         self.side = torch.cuda.Stream(device=device) if streams > 1 else None
         kind = 2 if acc == "dense" else 0
         g = torch.Generator(device=device)
@@ -165,11 +168,14 @@ class Stack:
                         self.tn_groups[ti].backward(tn_ph)
                 else:
                     self.tn_groups[ti].backward(tn_ph)
-                if self.deferred is not None and full:
+                if self.block_reduce is not None and full:
+                    self.block_reduce[ti].add_group(self.tn_groups[ti], tn_ph)
+                    self.block_reduce[ti].run()
+                elif self.deferred is not None and full:
                     self.deferred.add_group(self.tn_groups[ti], tn_ph)
         if self.side is not None and full:
             torch.cuda.current_stream().wait_stream(self.side)
-        if self.deferred is not None and full:
+        if self.deferred is not None and self.block_reduce is None and full:
             self.deferred.run()
 
     def step(self):
