@@ -446,8 +446,11 @@ def test_block_weight_gradients_row_owner_kernel(T):
         _, dA1, dB1, db1 = ops.sow_backward(dy, x, h1, A, B, None, None, 0.5, has_bias)
         ref.append((x, dy, A, B, dA1, dB1, db1))
     grp = ops.LayerGroup(calls)
-    grp.forward()
-    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)          # PARTIAL and REDUCE in one call: group-planned slabs
+    pinned = dict(NO_TN_ROWS=0, NO_GROUPED=0, TN_NARROW=0)   # the kernel under test, whatever the environment forces elsewhere
+    with _lib.switch(**pinned):
+        assert grp.weight_gradient_plan()[0]
+        grp.forward()
+        grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)          # PARTIAL and REDUCE in one call: group-planned slabs
     torch.cuda.synchronize()
     one_call = [(c._keep[7].clone(), c._keep[8].clone(), None if c._keep[9] is None else c._keep[9].clone()) for c in calls]
     worst = 0.0
@@ -468,10 +471,11 @@ def test_block_weight_gradients_row_owner_kernel(T):
             if g_ is not None:
                 g_.zero_()
     ph = _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS
-    grp.backward(ph)
-    red = ops.DeferredReduce()
-    red.add_group(grp, ph)
-    red.run()
+    with _lib.switch(**pinned):
+        grp.backward(ph)
+        red = ops.DeferredReduce()
+        red.add_group(grp, ph)
+        red.run()
     torch.cuda.synchronize()
     for c, (dA, dB, db) in zip(calls, one_call):
         assert torch.equal(c._keep[7], dA) and torch.equal(c._keep[8], dB)
@@ -509,14 +513,16 @@ def test_row_owner_kernel_random_groups(seed):
             out = (torch.zeros_like(A), torch.zeros_like(B), torch.zeros_like(bias) if hb else None)
             calls.append(ops.LayerCall(x, A, B, bias=bias, scale=1.5, dy2=dy, dx=torch.empty_like(x), out=out, grad_beta=0.0))
         grp = ops.LayerGroup(calls)
-        rows, slabs = grp.weight_gradient_plan()
+        with _lib.switch(NO_TN_ROWS=0, NO_GROUPED=0, TN_NARROW=0):      # whatever the environment forces elsewhere
+            rows, slabs = grp.weight_gradient_plan()
         if rows:
             break
         del calls, grp
         torch.cuda.empty_cache()
     assert rows, "no qualifying group drawn"
-    grp.forward()
-    grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
+    with _lib.switch(NO_TN_ROWS=0, NO_GROUPED=0, TN_NARROW=0):
+        grp.forward()
+        grp.backward(_lib.BWD_DATA | _lib.BWD_WEIGHTS)
     torch.cuda.synchronize()
     for c, (di, do, r, hb) in zip(calls, specs):
         x, A, B, dy = c._keep[0], c._keep[1], c._keep[2], c._keep[6]
