@@ -11,6 +11,10 @@
 // [D, r] or its transpose [r, D].
 // Column groups of one slab are NS blocks apart (NS % 8 == 0) so they share an XCD and S is served
 // from that XCD's L2 after the first read.
+// Kernels in this file: tn_partial_kernel (generic, any shape / dtype), tn_partial_dma_kernel (bf16, one column group per
+// block), tn_partial_dma_wide_kernel (bf16, two column groups per block; grouped + persistent: single layers and small
+// groups), tn_partial_rows_kernel (bf16, a workgroup owns ALL columns of a token slab: whole decoder blocks, slab counts
+// planned over the group), the fp32 forms (exact and 3 x bf16), and tn_reduce (fixed-order slab sum).
 #include "kernels.hpp"
 #include "lds_dma.hpp"
 #include <cstdlib>
