@@ -244,8 +244,23 @@ def cpu_baseline(shapes, T, r):
         O.sow_forward(x, [A], [B], None, None, 1.0, None)
         O.sow_backward(dy, x, [A], [B], None, None, 1.0, False)
     dt = time.perf_counter() - t0
-    return dict(value=T / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 fwd+bwd pass over the 56 llama_60m SoWLinear shapes, T={T}, fp32, torch-CPU oracle, {dt:.2f} s")
+    out = dict(value=T / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"1 fwd+bwd pass over the 56 llama_60m SoWLinear shapes, T={T}, fp32, torch-CPU oracle, {dt:.2f} s")
+    # the same oracle on ONE thread, bounded: the seven layers of one decoder block at T / 8 tokens, scaled to the stack
+    # (SURVEY 8(d) asks for both thread counts; the work per token does not depend on T)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    Ts = max(T // 8, 64)
+    t0 = time.perf_counter()
+    for s in shapes[:len(BLOCK_NAMES)]:
+        x, dy, A, B = cache[s]
+        O.sow_forward(x[:Ts], [A], [B], None, None, 1.0, None)
+        O.sow_backward(dy[:Ts], x[:Ts], [A], [B], None, None, 1.0, False)
+    dt1 = (time.perf_counter() - t0) * (len(shapes) / len(BLOCK_NAMES))
+    torch.set_num_threads(nthreads)
+    out["single_thread"] = dict(value=Ts / dt1, unit="tokens/s", cores=1,
+                                sample=f"one decoder block (7 layers) at T={Ts}, scaled x{len(shapes) // len(BLOCK_NAMES)} to the stack")
+    return out
 
 
 def train_mode(args, world, rank, device, steps=None, warmup=None, quiet=False):
