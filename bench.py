@@ -89,7 +89,30 @@ def parse():
                          "of the data-gradient kernels")
     ap.add_argument("--group", choices=["block", "none"], default="block",
                     help="block: {q,k,v} and {gate,up} of a decoder block share launches (grouped C-ABI calls); none: one call per layer")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="stop after torch.distributed is up: print {n_gpus, rccl} and exit (launcher / rendezvous rehearsal; with "
+                         "SOW_BENCH_BACKEND=gloo it needs no GPU)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start N ranks (one process per GPU) of
+    this same script under torch.distributed.run as a CHILD process -- before this process has made any GPU call; a process
+    that has initialised the GPU must never exec another program -- relay rank 0's JSON line and exit with the child's
+    code.  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` form sets WORLD_SIZE and never gets here.
+    Mirrors how the reference is launched (readme.md:6 torchrun --nproc-per-node, scripts/simple_train.py:229, 566-572)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
 
 
 class Stack:
@@ -181,6 +204,28 @@ class Stack:
     def step(self):
         self.forward_all()
         self.backward_all()
+
+    # ---- N > 1: backward cut per decoder block, so that a block's factor gradients can travel while the next block computes
+    def backward_block(self, ti):
+        """Data-gradient kernels of decoder block `ti` (groups in reverse), its weight-gradient partial sums and their
+        reduction: after this the block's slice of the flat gradient buffer is final (needs --reduce block)."""
+        from sow_amd import _lib
+        assert self.block_reduce is not None and self.side is None
+        for gi in reversed(range(len(self.groups))):
+            if self.group_layers[gi][0] in self.tn_layers[ti]:
+                self.groups[gi].backward(_lib.BWD_DATA)
+        tn_ph = _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS
+        self.tn_groups[ti].backward(tn_ph)
+        self.block_reduce[ti].add_group(self.tn_groups[ti], tn_ph)
+        self.block_reduce[ti].run()
+
+    def block_grad_range(self, ti):
+        """[start, end) elements of the flat gradient buffer that hold the factor gradients of decoder block `ti`
+        (the bucket's parameters are A, B per layer in layer order; the layers of a block are consecutive)."""
+        ids = self.tn_layers[ti]
+        lo, hi = 2 * min(ids), 2 * max(ids) + 2
+        offs = self.bucket.offsets
+        return offs[lo], (offs[hi] if hi < len(offs) else self.bucket.padded_numel)
 
 
 def algorithmic(shapes, T, r, es, acc):
@@ -503,21 +548,48 @@ def traffic_record(kernel_name):
     return None, None
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def init_distributed(args):
+    """world / rank / device of this process and, for world > 1, the process group.  Returns (world, rank, device, rccl)
+    where `rccl` records what actually came up: backend, world size and the ranks seen by an all-gather."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args)                 # never returns
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or "
+                 f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one process per GPU; ranks beyond the visible devices (a rehearsal of the N > 1 path on a 1-GPU box) share them
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("SOW_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (xGMI); "gloo" only for rehearsals
+    cpu_only = args.dry_run and backend != "nccl"
+    device = torch.device("cpu")
+    if not cpu_only:
+        # one process per GPU; ranks beyond the visible devices (a rehearsal of the N > 1 path on a 1-GPU box) share them
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    rccl = None
     if world > 1:
-        backend = os.environ.get("SOW_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (xGMI); "gloo" only for rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        seen = [None] * world
+        dist.all_gather_object(seen, rank)
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": sorted(int(r) for r in seen)}
+        assert dist.get_world_size() == args.gpus and rccl["ranks_seen"] == list(range(world)), rccl
+    return world, rank, device, rccl
+
+
+def main():
+    args = parse()
+    world, rank, device, rccl = init_distributed(args)
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl": rccl}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from sow_amd import _lib
     _lib.load()  # fail loudly when the HIP library is missing

@@ -97,8 +97,9 @@ class FactorBucket:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
-        self._work = None
+        self._works: list = []
         self._comm_stream: Optional[torch.cuda.Stream] = None
+        self._armed = True
         self._reducer = None
         self._sinks_pending: list = []
         self._off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
@@ -123,6 +124,10 @@ class FactorBucket:
         auto_all_reduce: issue the bucket's single all-reduce FROM BACKWARD, as soon as the last attached layer has
         queued its partial sums (the first SoW layer of the model: what is left of backward -- embedding gradients, DDP's
         own buckets for the non-factor parameters -- overlaps the collective); the step then only calls wait().
+        With gradient accumulation (simple_train.py:596-650 runs `gradient_accumulation` micro-batches per update) only
+        the LAST micro-batch's backward may reduce: run the others under `with bucket.no_sync():` (or
+        `bucket.require_sync(False)` before them and `require_sync(True)` before the last), exactly as with
+        DistributedDataParallel.no_sync().  A backward that arrives while a collective is pending raises.
 
         Autograd returns None for attached factors, so DistributedDataParallel must not manage them: attach BEFORE
         wrapping and call exclude_from_ddp(model) (a model that is already DDP-wrapped is refused)."""
@@ -154,9 +159,34 @@ class FactorBucket:
         torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, names)
         return names
 
+    def require_sync(self, flag: bool = True) -> None:
+        """Arm (default) or disarm the all-reduce-from-backward of attach(auto_all_reduce=True): disarmed backward passes
+        only accumulate into the local flat gradient buffer (non-final micro-batches of a gradient-accumulation step)."""
+        self._armed = bool(flag)
+
+    def no_sync(self):
+        """Context manager: backward passes inside accumulate locally and issue no collective (DDP.no_sync() analogue)."""
+        bucket = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.old = bucket._armed
+                bucket._armed = False
+
+            def __exit__(self_inner, *exc):
+                bucket._armed = self_inner.old
+                return False
+
+        return _NoSync()
+
     def _layer_done(self) -> None:
+        if self._works:
+            raise RuntimeError("FactorBucket: a backward pass reached an attached layer while the bucket's all-reduce is "
+                               "pending -- its gradients would be added on top of an already reduced buffer.  With gradient "
+                               "accumulation run the non-final micro-batches under `with bucket.no_sync():`; call wait() "
+                               "before the next armed backward")
         self._arrived += 1
-        if self._auto and self._n_attached and self._arrived == self._n_attached:
+        if self._auto and self._armed and self._n_attached and self._arrived % self._n_attached == 0:
             self.all_reduce_async(group=self._auto_group)
 
     def finalize(self) -> None:
@@ -189,39 +219,45 @@ class FactorBucket:
             self.flat_grad.zero_()
 
     # ------------------------------------------------------------------ collectives
-    def all_reduce_async(self, group=None, average: bool = True) -> None:
+    def all_reduce_async(self, group=None, average: bool = True, start: Optional[int] = None, end: Optional[int] = None) -> None:
         """One sum all-reduce of the whole factor-gradient bucket (RCCL over xGMI on GPUs, gloo on CPU
-        in the tests).  On GPU it runs on a side stream ordered after the current stream."""
-        self.finalize()
+        in the tests).  On GPU it runs on a side stream ordered after the current stream.  `start` / `end` (elements
+        of the flat buffer) restrict it to a slice -- e.g. the gradients of one decoder block, issued as soon as that
+        block's backward has been queued so that the exchange overlaps the rest of backward; several slices may be
+        in flight, wait() waits for all of them.  Without a slice the pending deferred reductions are finalized first."""
+        if start is None and end is None:
+            self.finalize()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
+        buf = self.flat_grad if (start is None and end is None) else self.flat_grad[(start or 0):(end if end is not None else self.padded_numel)]
         op = dist.ReduceOp.SUM
         if self.flat_grad.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=self.flat_grad.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(self.flat_grad.device))
             with torch.cuda.stream(self._comm_stream):
-                self._work = dist.all_reduce(self.flat_grad, op=op, group=group, async_op=True)
+                self._works.append(dist.all_reduce(buf, op=op, group=group, async_op=True))
         else:
-            self._work = dist.all_reduce(self.flat_grad, op=op, group=group, async_op=True)
+            self._works.append(dist.all_reduce(buf, op=op, group=group, async_op=True))
         self._average = average
         self._group = group
 
     def wait(self) -> float:
-        """Block the current stream on the collective; returns the scale the optimizer must apply to
+        """Block the current stream on the collective(s); returns the scale the optimizer must apply to
         the summed gradient (1/world for averaging -- folded into FactorAdamW.step(grad_scale))."""
         self._arrived = 0
-        if self._work is None:
+        if not self._works:
             if self._auto and dist.is_available() and dist.is_initialized() and dist.get_world_size(self._auto_group) > 1:
-                # not every attached layer ran backward this step (unused branch): reduce now
+                # not every attached layer ran backward this step (unused branch), or every backward ran disarmed: reduce now
                 self.all_reduce_async(group=self._auto_group)
-            if self._work is None:
+            if not self._works:
                 self.finalize()
                 return 1.0
-        self._work.wait()
+        for w in self._works:
+            w.wait()
         if self.flat_grad.is_cuda and self._comm_stream is not None:
             torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
-        self._work = None
+        self._works = []
         return 1.0 / dist.get_world_size(self._group) if self._average else 1.0
 
     def broadcast_factors(self, src: int = 0, group=None) -> None:

@@ -140,7 +140,15 @@ class FactorAdamW:
         self.exp_avg_sq = torch.zeros_like(bucket.flat_param, dtype=sd)
         self.step_count = 0
 
+    def _sync_from_group(self):
+        """Hyper-parameters written through param_groups[0] (what LR schedulers and drivers do: `group["lr"] = v`,
+        simple_train.py:537-563) are the ones the next step() uses and state_dict() saves."""
+        g = self.__dict__.get("_group")
+        if g is not None:
+            self.lr, self.betas, self.eps, self.weight_decay = g["lr"], g["betas"], g["eps"], g["weight_decay"]
+
     def step(self, grad_scale: float = 1.0):
+        self._sync_from_group()
         self.bucket.finalize()   # pending deferred weight-gradient reductions (FactorBucket.attach)
         for p, o in zip(self.bucket.params, self.bucket.offsets):
             if p.data_ptr() != self.bucket.flat_param.data_ptr() + o * self.bucket.flat_param.element_size():
@@ -159,19 +167,23 @@ class FactorAdamW:
     # ---- checkpoint / scheduler surface (simple_train.py:182, 537-563 save and restore optimizer + scheduler state)
     @property
     def param_groups(self):
-        """One group, torch.optim style: LR schedulers read and write group["lr"] (kept in sync with self.lr)."""
+        """One group, torch.optim style.  A driver's own scheduler code (`for g in opt.param_groups: g["lr"] = lr`) works on
+        it: step() and state_dict() read the group's values.  torch.optim.lr_scheduler classes insist on a real
+        torch.optim.Optimizer instance and do not accept this object -- drive the factor lr from the loop instead (the
+        reference computes its schedule with a LambdaLR over the torch optimizer; read `scheduler.get_last_lr()` and write
+        it here)."""
         if not hasattr(self, "_group"):
             self._group = {"params": self.bucket.params, "lr": self.lr, "betas": self.betas, "eps": self.eps,
                            "weight_decay": self.weight_decay}
         else:
-            self.lr, self.betas = self._group["lr"], self._group["betas"]
-            self.eps, self.weight_decay = self._group["eps"], self._group["weight_decay"]
+            self._sync_from_group()
         return [self._group]
 
     def zero_grad(self, set_to_none: bool = False):
         self.bucket.zero_grad()
 
     def state_dict(self):
+        self._sync_from_group()
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                 "numel": self.bucket.padded_numel}

@@ -330,11 +330,16 @@ assert sorted(ignored) == ["l1.downscale_weights.0", "l1.upscale_weights.0", "l2
 ddp = nn.parallel.DistributedDataParallel(net)           # reduces head.* only
 bucket._n_attached, bucket._auto = 2, True              # what attach(model, auto_all_reduce=True) sets on the GPU
 (ddp(X[4 * rank: 4 * rank + 4]) ** 2).sum().backward()  # autograd accumulates in place into the flat-buffer views
-assert bucket._work is None
+assert not bucket._works
 bucket._layer_done()                                     # l2's sink ...
-assert bucket._work is None
+assert not bucket._works
 bucket._layer_done()                                     # ... l1's sink: the LAST attached layer issues the all-reduce
-assert bucket._work is not None
+assert len(bucket._works) == 1
+try:
+    bucket._layer_done()                                 # a further backward before wait(): refused, not silently mis-summed
+    raise SystemExit("backward during a pending all-reduce was not refused")
+except RuntimeError as e:
+    assert "no_sync" in str(e)
 scale = bucket.wait()
 assert abs(scale - 0.5) < 1e-12 and bucket._arrived == 0
 (ref(X) ** 2).sum().backward()
@@ -385,6 +390,101 @@ def test_bucket_protocol_with_ddp_gloo_world2(tmp_path):
         assert f"rank {r} ok" in o
 
 
+_DP_GA_WORKER = r'''
+import copy, os, sys, torch, torch.distributed as dist
+root = sys.argv[3]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+rank, world = int(sys.argv[1]), 2
+dist.init_process_group("gloo", init_method="file://" + sys.argv[2], rank=rank, world_size=world)
+import torch.nn as nn
+from oracle_backend import OracleSoWLinear
+from sow_amd import FactorBucket
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.l1 = OracleSoWLinear(12, 10, False, 4, 0.5, "normal")
+        self.l2 = OracleSoWLinear(10, 6, False, 4, 0.5, "normal")
+        self.head = nn.Linear(6, 3)
+    def forward(self, x):
+        return self.head(self.l2(torch.tanh(self.l1(x))))
+
+torch.manual_seed(0)
+net = Net()
+for m in (net.l1, net.l2):
+    nn.init.normal_(m.downscale_weights[0], std=0.3); nn.init.normal_(m.upscale_weights[0], std=0.3)
+ref = copy.deepcopy(net)
+X = torch.randn(8, 12)
+factors = [net.l1.downscale_weights[0], net.l1.upscale_weights[0], net.l2.downscale_weights[0], net.l2.upscale_weights[0]]
+bucket = FactorBucket(factors)
+bucket.exclude_from_ddp(net)
+ddp = nn.parallel.DistributedDataParallel(net)
+bucket._n_attached, bucket._auto = 2, True              # what attach(model, auto_all_reduce=True) sets on the GPU
+mine = X[4 * rank: 4 * rank + 4]
+# gradient accumulation = 2 (simple_train.py:596-650): micro-batch 1 local only, micro-batch 2 reduces
+with ddp.no_sync(), bucket.no_sync():
+    (ddp(mine[:2]) ** 2).sum().backward()
+    bucket._layer_done(); bucket._layer_done()
+    assert not bucket._works and bucket._arrived == 2
+(ddp(mine[2:]) ** 2).sum().backward()
+bucket._layer_done()
+assert not bucket._works
+bucket._layer_done()                                     # 2 micro-batches x 2 layers arrived, armed: ONE collective
+assert len(bucket._works) == 1
+scale = bucket.wait()
+assert abs(scale - 0.5) < 1e-12 and bucket._arrived == 0 and not bucket._works
+(ref(X) ** 2).sum().backward()
+ref_f = [ref.l1.downscale_weights[0], ref.l1.upscale_weights[0], ref.l2.downscale_weights[0], ref.l2.upscale_weights[0]]
+for p, q in zip(factors, ref_f):
+    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (p.grad - q.grad).abs().max()   # both micro-batches of both ranks
+assert torch.allclose(net.head.weight.grad, ref.head.weight.grad / world, rtol=1e-5, atol=1e-6)
+# every backward disarmed (a loop that forgot to re-arm): wait() still reduces, nothing is lost
+bucket.zero_grad()
+with ddp.no_sync(), bucket.no_sync():
+    (ddp(mine) ** 2).sum().backward()
+    bucket._layer_done(); bucket._layer_done()
+assert not bucket._works
+assert abs(bucket.wait() - 0.5) < 1e-12
+for p, q in zip(factors, ref_f):
+    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_bucket_gradient_accumulation_gloo_world2(tmp_path):
+    """Gradient accumulation > 1 with the all-reduce issued from backward: the non-final micro-batches run under
+    bucket.no_sync() (and DDP's no_sync()), the final one fires ONE collective over the locally accumulated buffer;
+    the result equals the single-process gradient on the concatenated batch of both ranks and both micro-batches."""
+    store = str(tmp_path / "store")
+    script = str(tmp_path / "worker.py")
+    open(script, "w").write(_DP_GA_WORKER)
+    procs = [subprocess.Popen([sys.executable, script, str(r), store, ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_bench_launcher_starts_n_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment starts 2 ranks as a child process (config 3's
+    launch form, reference readme.md:6 / simple_train.py:229) -- rehearsed on CPU with gloo, stopping after the process
+    group is up; a WORLD_SIZE that contradicts --gpus is refused."""
+    env = dict(os.environ, SOW_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                         text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_seen": [0, 1]}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True,
+                         text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=120, cwd=str(tmp_path))
+    assert bad.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in bad.stderr
+
+
 def test_attach_refuses_a_ddp_wrapped_model_and_optimizer_state_round_trips():
     from sow_amd import FactorBucket, SoWLinear, factor_parameters
     from sow_amd.optimizer import FactorAdamW
@@ -403,8 +503,8 @@ def test_attach_refuses_a_ddp_wrapped_model_and_optimizer_state_round_trips():
     opt.step_count = 7
     opt.param_groups[0]["lr"] = 1e-3            # what an LR scheduler does
     sd = opt.state_dict()
-    assert sd["lr"] == 3e-3                     # not yet synced: schedulers' writes take effect on the next read of param_groups
-    assert opt.param_groups[0]["lr"] == 1e-3 and opt.lr == 1e-3
+    assert sd["lr"] == 1e-3 and opt.lr == 1e-3  # the written value is the one saved (and the one the next step() uses)
+    assert opt.param_groups[0]["lr"] == 1e-3
     other = FactorAdamW(bucket, state_dtype=torch.float32)
     other.load_state_dict(opt.state_dict())
     assert other.step_count == 7 and other.lr == 1e-3 and other.betas == (0.9, 0.95) and other.weight_decay == 0.1
