@@ -458,49 +458,98 @@ def per_launch_table(stack, stream, T, r, es):
     return table
 
 
-def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, detail):
-    """Build the stack, capture the step, time `steps` replays (barrier + synchronize on both sides, max over ranks)."""
+def _stats(ms_list):
+    v = sorted(ms_list)
+    n = len(v)
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"median": med, "min": v[0], "max": v[-1], "mean": sum(v) / n, "per_replay_ms": [round(x, 4) for x in ms_list]}
+
+
+def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, detail, warm_replays=5):
+    """Build the stack, capture the step, time `steps` replays (barrier + synchronize on both sides, max over ranks).
+    Every replay is also bracketed by HIP events on the launch stream (`replays`: median / min / max / per-replay list), so a
+    record shows whether a slow figure was one stall or a uniform slowdown.
+
+    N > 1: the step is cut into a forward graph and one backward graph per decoder block (last block first); after each
+    block's graph the all-reduce of THAT block's slice of the flat factor-gradient bucket is issued on the bucket's side
+    stream, so the exchange of block b overlaps the backward of blocks b-1 ... 0 (what DDP's gradient buckets do for the
+    reference, simple_train.py:566-572); the step ends when the last slice has arrived."""
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     es = 2 if dtype_name == "bf16" else 4
     shapes = layer_shapes()
     T = args.tokens
-    stack = Stack(shapes, T, args.rank, dtype, device, acc, args.reduce, args.group, args.tn_group, args.streams)
+    overlap = world > 1 and args.group == "block" and args.tn_group == "block" and args.streams == 1
+    reduce_mode = "block" if overlap else args.reduce
+    stack = Stack(shapes, T, args.rank, dtype, device, acc, reduce_mode, args.group, args.tn_group, args.streams)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.synchronize()
+    nblk = len(stack.tn_layers)
 
-    def comm():
-        if world > 1:
-            stack.bucket.all_reduce_async()
+    def eager_step():
+        if overlap:
+            stack.forward_all()
+            for ti in reversed(range(nblk)):
+                stack.backward_block(ti)
+                stack.bucket.all_reduce_async(start=stack.block_grad_range(ti)[0], end=stack.block_grad_range(ti)[1])
             stack.bucket.wait()
+        else:
+            stack.step()
+            if world > 1:
+                stack.bucket.all_reduce_async()
+                stack.bucket.wait()
 
-    graph = None
+    graphs = None
     res = {}
     with torch.cuda.stream(stream):
         for _ in range(max(warmup, 1)):   # W untimed warm-up steps (also sets kernel attributes)
-            stack.step()
-            comm()
+            eager_step()
         torch.cuda.synchronize()
         if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                stack.step()
-            graph.replay()
-            comm()
-            torch.cuda.synchronize()
+            def capture(fn):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    fn()
+                return g
+            if overlap:
+                graphs = [capture(stack.forward_all)] + [capture(lambda ti=ti: stack.backward_block(ti)) for ti in reversed(range(nblk))]
+            else:
+                graphs = [capture(stack.step)]
 
         def one_step():
-            if graph is not None:
-                graph.replay()
+            if graphs is None:
+                eager_step()
+            elif overlap:
+                graphs[0].replay()
+                for k, ti in enumerate(reversed(range(nblk))):
+                    graphs[1 + k].replay()
+                    lo, hi = stack.block_grad_range(ti)
+                    stack.bucket.all_reduce_async(start=lo, end=hi)
+                stack.bucket.wait()
             else:
-                stack.step()
-            comm()
+                graphs[0].replay()
+                if world > 1:
+                    stack.bucket.all_reduce_async()
+                    stack.bucket.wait()
 
+        # warm replays: graph upload, caches and the chip's clock / power state (an MFMA-heavy step needs ~10 replays to
+        # settle: the first dense replays of a fresh process measured 7.9, 7.5, 7.1, 7.0, 6.9 ... 6.72 ms): at least
+        # `warm_replays` and at least 0.25 s of them
+        t_warm = time.perf_counter()
+        n_warm = 0
+        while graphs is not None and (n_warm < warm_replays or time.perf_counter() - t_warm < 0.25) and n_warm < 200:
+            one_step()
+            torch.cuda.synchronize()
+            n_warm += 1
+        res["warm_replays"] = n_warm
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        ev[0].record(stream)
+        for i in range(steps):
             one_step()
+            ev[i + 1].record(stream)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -511,14 +560,16 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
             elapsed = float(tmax.item())
         ms = elapsed / steps * 1e3
         flops, nbytes = algorithmic(shapes, T, args.rank, es, acc)
-        res.update(ms_per_step=ms, flops=flops, nbytes=nbytes, graph=graph is not None, T=T, shapes=shapes, es=es)
+        res.update(ms_per_step=ms, flops=flops, nbytes=nbytes, graph=graphs is not None, T=T, shapes=shapes, es=es,
+                   replays=_stats([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]), overlap=overlap)
         if rank == 0 and detail:
             it = max(3, min(steps, 10))
             nl = len(stack.groups)
             res["fwd_ms"] = time_region(stack.forward_all, it, stream)
-            res["bwd_ms"] = time_region(stack.backward_all, it, stream)
+            res["bwd_ms"] = time_region(stack.backward_all if not overlap else
+                                        (lambda: [stack.backward_block(ti) for ti in reversed(range(nblk))]), it, stream)
             res["n_fwd_launches"] = nl
-            if acc == "none" and dtype_name == "bf16":
+            if acc == "none" and dtype_name == "bf16" and not overlap:
                 res["per_launch"] = per_launch_table(stack, stream, T, args.rank, es)
             if acc == "dense":
                 # layers whose forward is exactly ONE gemm2h launch (N <= 512: 40 of the 56); flops of one launch =
@@ -529,10 +580,68 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
                 fl = sum(2 * T * shapes[i][0] * shapes[i][1] + 2 * T * args.rank * (shapes[i][0] + shapes[i][1])
                          for gi in one for i in stack.group_layers[gi])
                 res["gemm2h"] = dict(avg_launch_ms=t / n_l, launches=n_l, tflops=fl / (t * 1e-3) / 1e12)
-    del stack, graph
+    del stack, graphs
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+def northstar(device, reps=20, warm=5):
+    """BASELINE.json north_star point: ONE SoWLinear forward + backward at r = 50, d_in = d_out = 768, T = 32768, in bf16 and
+    in fp32, through the single-layer C-ABI calls (sow_forward, sow_backward), 4 rotating buffer sets in one HIP graph so that
+    no replay finds its inputs in the Infinity Cache; per-replay HIP events.  Flops = 6*T*r*(d_in+d_out) (SURVEY 8d);
+    algorithmic bytes = T*(3 d_in + 2 d_out + 2 r)*s.  `frac` = TFLOP/s over the MFMA peak of the tensors' dtype (2.5 PF bf16,
+    157 TF fp32); `frac_of_roofline` = over min(that peak, AI x 8 TB/s)."""
+    from sow_amd import _lib, ops
+    T, d, r, nset = 32768, 768, 50, 4
+    out = {"what": f"one SoWLinear fwd+bwd, T={T}, d_in=d_out={d}, rank={r} (BASELINE.json north_star)"}
+    g = torch.Generator(device=device).manual_seed(77)
+    for name, dtype, peak in (("bf16", torch.bfloat16, MFMA_BF16_TFLOPS), ("fp32", torch.float32, MFMA_F32_TFLOPS)):
+        es = 2 if dtype == torch.bfloat16 else 4
+        xs = [torch.randn(T, d, device=device, generator=g).to(dtype) for _ in range(nset)]
+        dys = [torch.randn(T, d, device=device, generator=g).to(dtype) for _ in range(nset)]
+        A = torch.linalg.qr(torch.randn(d, r, generator=g, device=device).cpu() * 0.02)[0].to(device).to(dtype).contiguous()
+        B = (torch.randn(r, d, device=device, generator=g) * 0.02).to(dtype)
+
+        def step():
+            for i in range(nset):
+                _, h = ops.sow_forward(xs[i], A, B, None, None, None, 1.0)
+                ops.sow_backward(dys[i], xs[i], h, A, B, None, None, 1.0, False)
+
+        s = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(s):
+            step()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                step()
+            for _ in range(warm):
+                gr.replay()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            ev[0].record(s)
+            for i in range(reps):
+                gr.replay()
+                ev[i + 1].record(s)
+            torch.cuda.synchronize()
+        st = _stats([ev[i].elapsed_time(ev[i + 1]) / nset for i in range(reps)])
+        us = st["median"] * 1e3
+        flops = 6 * T * r * 2 * d
+        nbytes = T * (3 * d + 2 * d) * es + 2 * T * r * es
+        tf = flops / us / 1e6
+        ai = flops / nbytes
+        roof = min(peak, ai * HBM_PEAK_GBS / 1e3)
+        rec = {"us": us, "us_min": st["min"] * 1e3, "us_max": st["max"] * 1e3, "tflops": tf, "peak_tflops": peak, "frac": tf / peak,
+               "algorithmic_MB": nbytes / 1e6, "hbm_gbs": nbytes / us / 1e3, "hbm_frac": nbytes / us / 1e3 / HBM_PEAK_GBS,
+               "arithmetic_intensity": ai, "roofline_tflops": roof, "frac_of_roofline": tf / roof}
+        if name == "fp32":
+            exact = _lib.load().sow_get_switch(b"F32_EXACT") == 1
+            rec["form"] = "exact (v_mfma_f32_32x32x2_f32)" if exact else "3xbf16 (fp32 operands split into three bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-equivalent results, runs on the bf16 matrix pipe)"
+            rec["peak_note"] = "frac divides by the 157 TF fp32 matrix peak, the figure BASELINE.json's target is stated against"
+        out[name] = rec
+        del xs, dys
+    torch.cuda.empty_cache()
+    return out
 
 
 def traffic_record(kernel_name):
@@ -639,7 +748,7 @@ def main():
             "config": {"workload": "llama_60m --architecture sow: 56 SoWLinear layers (32x512->512, 16x512->1376, 8x1376->512), "
                                    f"rank {args.rank}, batch 128 x seq 256 = {T} tokens/GPU, fwd+bwd, acc={args.acc}",
                        "tokens_per_gpu": T, "rank": args.rank, "parallelism": f"dp{world}", "hip_graph": head["graph"],
-                       "weight_grad_reduce": args.reduce, "streams": args.streams,
+                       "weight_grad_reduce": "block" if head["overlap"] else args.reduce, "streams": args.streams,
                        "launch_grouping": ("per decoder block: {q,k,v} {o} {gate,up} {down} for the chain kernels, all 7 layers for the "
                                            "weight-gradient partial sums; resident (persistent) workgroups") if args.group == "block" else "one call per layer"},
             "gflops": head["flops"] * world / (ms * 1e-3) / 1e9,
@@ -652,24 +761,40 @@ def main():
         }
         if "per_launch" in head:
             out["per_launch"] = head["per_launch"]
+    if rank == 0:
+        out["replays"] = head["replays"]
+        if rccl is not None:
+            out["rccl"] = dict(rccl, overlap=("per-decoder-block slices of the factor-gradient bucket, each all-reduced on a side stream "
+                                              "while the next block's backward runs") if head["overlap"] else "one all-reduce after backward")
     extras = world == 1 and not args.only_headline and args.dtype == "bf16" and args.acc == "none"
     if extras:
-        k = max(3, min(args.steps, 10))
-        d = measure_stack(args, "bf16", "dense", 1, 0, device, k, 2, detail=True)
+        k = max(20, args.steps)
+        d = measure_stack(args, "bf16", "dense", 1, 0, device, k, max(args.warmup, 2), detail=True)
         g2h = d["gemm2h"]
+        dms = d["replays"]["median"]
         out["dense"] = {
             "what": "steady state after the first accumulate(): dense frozen accumulator + live rank-50 factors (prepare.py:120)",
-            "ms_per_step": d["ms_per_step"], "steps": k, "tokens_per_s": T / (d["ms_per_step"] * 1e-3),
-            "tflops": d["flops"] / (d["ms_per_step"] * 1e-3) / 1e12,
-            "frac_of_bf16_mfma_peak": d["flops"] / (d["ms_per_step"] * 1e-3) / 1e12 / MFMA_BF16_TFLOPS,
+            "ms_per_step": dms, "ms_per_step_note": f"median of {k} graph replays after 5 warm replays, HIP events per replay",
+            "steps": k, "replays": d["replays"], "wallclock_ms_per_step": d["ms_per_step"],
+            "fwd_ms": d["fwd_ms"], "bwd_ms": d["bwd_ms"], "tokens_per_s": T / (dms * 1e-3),
+            "tflops": d["flops"] / (dms * 1e-3) / 1e12,
+            "frac_of_bf16_mfma_peak": d["flops"] / (dms * 1e-3) / 1e12 / MFMA_BF16_TFLOPS,
             "roofline": {"bound": "mfma", "kernel": "sow::gemm2h_kernel<false> (one launch per forward pass, N <= 512)",
                          "achieved": g2h["tflops"], "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": g2h["tflops"] / MFMA_BF16_TFLOPS, "traffic": None, "avg_launch_ms": g2h["avg_launch_ms"],
                          "launches_timed": g2h["launches"]}}
-        f = measure_stack(args, "f32", "none", 1, 0, device, max(3, min(args.steps, 5)), 2, detail=False)
-        out["fp32"] = {"what": "the same stack in exact fp32 (the 1e-5 parity path)", "ms_per_step": f["ms_per_step"],
-                       "tflops": f["flops"] / (f["ms_per_step"] * 1e-3) / 1e12,
-                       "frac_of_fp32_mfma_peak": f["flops"] / (f["ms_per_step"] * 1e-3) / 1e12 / MFMA_F32_TFLOPS}
+        f = measure_stack(args, "f32", "none", 1, 0, device, k, 2, detail=True)
+        fms = f["replays"]["median"]
+        x3 = _lib.load().sow_get_switch(b"F32_EXACT") != 1
+        out["fp32"] = {"what": "the same stack on fp32 tensors (the 1e-5 parity path)",
+                       "form": ("3xbf16: fp32 operands split into three bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate "
+                                "(fp32-equivalent; runs on the bf16 matrix pipe)") if x3 else "exact: v_mfma_f32_32x32x2_f32",
+                       "ms_per_step": fms, "steps": k, "replays": f["replays"], "fwd_ms": f["fwd_ms"], "bwd_ms": f["bwd_ms"],
+                       "tflops": f["flops"] / (fms * 1e-3) / 1e12,
+                       "frac_of_fp32_mfma_peak": f["flops"] / (fms * 1e-3) / 1e12 / MFMA_F32_TFLOPS,
+                       "peak_note": "flop count over the 157 TF fp32 matrix peak (the figure the target is stated against), "
+                                    "whichever pipe the products run on"}
+        out["northstar"] = northstar(device)
         try:
             t = train_mode(args, 1, 0, device, steps=max(3, min(args.steps, 10)), warmup=3, quiet=True)
             out["train"] = {"what": t["config"]["workload"], "ms_per_step": t["ms_per_step"], "tokens_per_s": t["value"],

@@ -574,7 +574,7 @@ int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stre
     if ((rc = check_layer(L, false))) return rc;
     if (L.T == 0) continue;
     const WsPlan w{};
-    if (L.h_save && group_chain_params(L, false, dtype, w, &batch[nb])) {
+    if (group_chain_params(L, false, dtype, w, &batch[nb])) {   // h_save may be NULL (no backward follows)
       if (++nb == C2_MAXG) {
         if ((rc = launch_chain2_group(batch, nb, false, stream))) return rc;
         nb = 0;

@@ -33,15 +33,17 @@ class _SoWGroupFunction(torch.autograd.Function):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         per = [tensors[5 * i:5 * i + 5] for i in range(n)]
+        need_bwd = any(ctx.needs_input_grad)
         calls = []
         for (A, B, acc_down, acc_up, bias), s in zip(per, scales):
             kind = ops.acc_kind(acc_down, acc_up)
             calls.append(ops.LayerCall(x2, A.contiguous(), B.contiguous(),
                                        acc_down=acc_down.contiguous() if kind != _lib.ACC_NONE else None,
                                        acc_up=acc_up.contiguous() if kind == _lib.ACC_LOWRANK else None,
-                                       bias=bias, scale=s, forward_only=True))
+                                       bias=bias, scale=s, forward_only=True, save_h=need_bwd))
         ops.LayerGroup(calls).forward()
-        ctx.save_for_backward(x2, *[c.h for c in calls], *tensors)
+        if need_bwd:
+            ctx.save_for_backward(x2, *[c.h for c in calls], *tensors)
         ctx.scales, ctx.n, ctx.x_shape = scales, n, x.shape
         return tuple(c.y.reshape(*lead, c.y.shape[1]) for c in calls)
 
@@ -92,6 +94,13 @@ class SiblingGroup:
             return False
         for m in self.layers:
             if m.n_iter != 1 or getattr(m, "_grad_sink", None) is not None or m.downscale_weights[0].dtype != x.dtype:
+                return False
+            # an accumulator the grouped launch cannot take as it stands (dtype / shape / device of a checkpoint that was
+            # loaded in another precision, load_sow): the layer runs on its own and raises exactly what the ungrouped
+            # call raises
+            try:
+                ops.check_accumulator(x, m.in_features, m.out_features, m.acc_downweight, m.acc_upweight)
+            except (TypeError, ValueError, RuntimeError):
                 return False
         return True
 

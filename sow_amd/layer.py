@@ -141,6 +141,13 @@ class SoWLinear(nn.Module):
             if y is not None:
                 return y
         A, B = self._cat_factors()
+        if not (torch.is_grad_enabled() and (x.requires_grad or A.requires_grad or B.requires_grad
+                                             or (self.bias is not None and self.bias.requires_grad))):
+            # no backward will follow (eval / generate, commonsense_evaluate.py:268-287; the first pass of activation
+            # checkpointing): the projection h = scale * x A is not written to HBM
+            x2 = x.reshape(-1, x.shape[-1])
+            y, _ = ops.sow_forward(x2, A, B, self.acc_downweight, self.acc_upweight, self.bias, float(self.scale), save_h=False)
+            return y.reshape(*x.shape[:-1], B.shape[1])
         return _SoWFunction.apply(x, A, B, self.acc_downweight, self.acc_upweight, self.bias, float(self.scale),
                                   getattr(self, "_grad_sink", None))
 

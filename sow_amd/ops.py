@@ -101,8 +101,35 @@ def acc_kind(acc_down: Optional[torch.Tensor], acc_up: Optional[torch.Tensor]) -
     return _lib.ACC_LOWRANK
 
 
-def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, acc_up, bias, scale: float):
-    """y, h_save = forward of the SoW contraction on a flattened [T, d_in] input."""
+def check_accumulator(x2: torch.Tensor, d_in: int, d_out: int, acc_down, acc_up, who: str = "sow_amd") -> Tuple[int, int]:
+    """(acc_kind, r_acc) after the checks every entry point applies before raw pointers reach the kernels: the
+    accumulator has the input's dtype (TypeError), the shapes of its kind (ValueError), lives on the input's device and is
+    dense row-major.  A mismatch that got through would be read as the wrong type -- silent garbage for an fp32
+    accumulator under bf16 inputs, an out-of-bounds device read the other way round."""
+    kind = acc_kind(acc_down, acc_up)
+    if kind == _lib.ACC_NONE:
+        return kind, 0
+    r_acc = 0
+    if acc_down.dtype != x2.dtype or (kind == _lib.ACC_LOWRANK and acc_up.dtype != x2.dtype):
+        bad = acc_down.dtype if acc_down.dtype != x2.dtype else acc_up.dtype
+        raise TypeError(f"{who}: dtype mismatch, x is {x2.dtype} but the accumulator is {bad}")
+    if kind == _lib.ACC_DENSE and tuple(acc_down.shape) != (d_in, d_out):
+        raise ValueError(f"{who}: dense accumulator must be [in_features, out_features]")
+    if kind == _lib.ACC_LOWRANK:
+        r_acc = acc_down.shape[1] if acc_down.dim() == 2 else -1
+        if acc_down.dim() != 2 or acc_down.shape[0] != d_in or tuple(acc_up.shape) != (r_acc, d_out):
+            raise ValueError(f"{who}: low-rank accumulator shapes do not match")
+    for t in (acc_down, acc_up if kind == _lib.ACC_LOWRANK else None):
+        if t is not None and (not t.is_cuda or t.device != x2.device):
+            raise RuntimeError(f"{who}: the accumulator is on {t.device}, the input on {x2.device}")
+    return kind, r_acc
+
+
+def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, acc_up, bias, scale: float,
+                save_h: bool = True):
+    """y, h_save = forward of the SoW contraction on a flattened [T, d_in] input.  save_h = False (no-grad / eval callers,
+    e.g. the reload + generate loop of commonsense_evaluate.py:268-287): the projection is not written to HBM and None
+    is returned in its place (r <= 64; wider ranks compose two GEMMs and need the buffer as their intermediate)."""
     lib = _lib.load()
     dev = _need_gpu(x2, A, B, acc_down if acc_down is not None and acc_down.numel() else None,
                     acc_up if acc_up is not None and acc_up.numel() else None, bias)
@@ -114,29 +141,22 @@ def sow_forward(x2: torch.Tensor, A: torch.Tensor, B: torch.Tensor, acc_down, ac
     r, d_out = B.shape
     if A.shape != (d_in, r):
         raise ValueError(f"sow_amd: A has shape {tuple(A.shape)}, expected {(d_in, r)}")
-    kind = acc_kind(acc_down, acc_up)
-    r_acc = 0
-    if kind == _lib.ACC_DENSE and tuple(acc_down.shape) != (d_in, d_out):
-        raise ValueError("sow_amd: dense accumulator must be [in_features, out_features]")
-    if kind == _lib.ACC_LOWRANK:
-        r_acc = acc_down.shape[1]
-        if acc_down.shape[0] != d_in or tuple(acc_up.shape) != (r_acc, d_out):
-            raise ValueError("sow_amd: low-rank accumulator shapes do not match")
-    if kind != _lib.ACC_NONE and acc_down.dtype != x2.dtype:
-        raise TypeError(f"sow_amd: dtype mismatch, x is {x2.dtype} but the accumulator is {acc_down.dtype}")
+    kind, r_acc = check_accumulator(x2, d_in, d_out, acc_down, acc_up)
     x2 = x2.contiguous()
     A, B = A.contiguous(), B.contiguous()
     acc_down = acc_down.contiguous() if kind != _lib.ACC_NONE else None
     acc_up = acc_up.contiguous() if kind == _lib.ACC_LOWRANK else None
     bias = bias.contiguous() if bias is not None else None
     y = torch.empty((T, d_out), dtype=x2.dtype, device=dev)
-    h = torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)   # == sow_h_save_elems(T, r)
+    h = None
+    if save_h or r > 64:
+        h = torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)   # == sow_h_save_elems(T, r)
     # the forward touches a workspace only for some shapes (include/sow_amd.h: sow_forward_workspace_bytes)
     nws = _forward_workspace_bytes(lib, T, d_in, d_out, r, r_acc, kind, dt)
     ws = _ws(nws, dev) if nws else None
     _launch(dev, "sow_forward", lib.sow_forward, _ptr(x2), _ptr(A), _ptr(B), _ptr(acc_down), _ptr(acc_up), _ptr(bias), _ptr(y),
             _ptr(h), T, d_in, d_out, r, r_acc, kind, float(scale), dt, _ptr(ws), 0 if ws is None else ws.numel())
-    return y, h
+    return y, (h if save_h else None)
 
 
 def workspace_bytes(T: int, d_in: int, d_out: int, r: int, r_acc: int, kind: int, dtype: torch.dtype) -> int:
@@ -187,20 +207,25 @@ class LayerCall:
     own workspace (workspace_bytes())."""
 
     def __init__(self, x2, A, B, *, acc_down=None, acc_up=None, bias=None, scale=1.0, y=None, h=None, dy2=None, dx=None,
-                 out=None, grad_beta=0.0, workspace=None, forward_only=False):
+                 out=None, grad_beta=0.0, workspace=None, forward_only=False, save_h=True):
         dev = _need_gpu(x2, A, B, bias, y, h, dy2, dx, workspace)
         self.dtype = _dt(x2)
         T, d_in = x2.shape
         r, d_out = B.shape
-        kind = acc_kind(acc_down, acc_up)
-        for name, t in (("x", x2), ("A", A), ("B", B), ("bias", bias), ("y", y), ("dy", dy2), ("dx", dx)):
+        # the same accumulator checks as the single-layer entry point (ops.sow_forward): same exceptions for the same input
+        kind, _ = check_accumulator(x2, d_in, d_out, acc_down, acc_up, "sow_amd.LayerCall")
+        for name, t in (("x", x2), ("A", A), ("B", B), ("bias", bias), ("y", y), ("dy", dy2), ("dx", dx),
+                        ("acc_down", acc_down if kind != _lib.ACC_NONE else None),
+                        ("acc_up", acc_up if kind == _lib.ACC_LOWRANK else None)):
             if t is not None and (not t.is_contiguous() or t.dtype != x2.dtype):
                 raise ValueError(f"sow_amd.LayerCall: {name} must be contiguous and of the input dtype")
         if A.shape != (d_in, r):
             raise ValueError("sow_amd.LayerCall: factor shapes do not match the input")
         self.device, self.kind = dev, kind
         self.y = y if y is not None else torch.empty((T, d_out), dtype=x2.dtype, device=dev)
-        self.h = h if h is not None else torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)
+        # save_h = False (forward_only calls that no backward follows): h_save = NULL, the projection stays on chip
+        self.h = h if h is not None else (torch.empty(T * (64 if r <= 64 else r), dtype=x2.dtype, device=dev)
+                                          if (save_h or r > 64 or not forward_only) else None)
         self.dx = dx
         r_acc = acc_down.shape[1] if kind == _lib.ACC_LOWRANK else 0
         # a forward-only call needs scratch for a few shapes only (sow_forward_workspace_bytes), often none at all
