@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
                                                    "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
-                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS"};
+                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -41,7 +41,7 @@ static void switches_from_env() {
     snprintf(name, sizeof name, "SOW_AMD_%s", kSwitchNames[i]);
     const char* v = getenv(name);
     // tri-state switches take "0" / "1"; for the boolean ones any value (even empty) means on, as before
-    const bool tri = i == SW_GEMM3S || i == SW_GEMM3;
+    const bool tri = i == SW_GEMM3S || i == SW_GEMM3 || i == SW_GEMM4;
     g_switch[i].store(!v ? -1 : (tri ? (v[0] != '0') : 1), std::memory_order_relaxed);
   }
 }

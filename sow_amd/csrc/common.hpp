@@ -138,6 +138,7 @@ enum Switch : int {
   SW_NO_PARK16,           // chain kernel parks output slices as fp32 even when bf16 would be exact
   SW_TN_NO_NT_LOAD,       // row-owner weight-gradient kernel streams x / dY with plain (cached) loads
   SW_NO_TN_ROWS,          // grouped weight-gradient launches never use the row-owner kernel (group-planned slabs)
+  SW_GEMM4,               // 1 / 0: force / forbid gemm4 (anti-phase wave groups, 64-wide K-tiles)
   SW_COUNT
 };
 int sw(int which);

@@ -268,6 +268,14 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   const int64_t tiles = (int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+  // gemm4 (anti-phase wave groups, 64-wide K-tiles): 15-30 % faster than the kernels below wherever its 256 x 256 tiles
+  // fill at least half of the chip (profiles/r03_gemm4_vs_round2_vs_hipblaslt.txt: 4096^3 1.38 vs 0.97-1.03 PF, 32768 x 512
+  // -> 1376 58 vs 72 us); with fewer tiles (M = 1024 x N = 4096: 64) the 128 x 128 tiles of gemm3s fill more CUs.
+  // GEMM4 = 1 forces it on every supported shape, 0 forbids it.
+  const int g4 = sw(SW_GEMM4);
+  if ((g4 > 0 || (g4 < 0 && tiles >= 120 && K >= 64)) &&
+      gemm4_supported(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, C, ldc, bias, M, N, K, SOW_BF16))
+    return launch_gemm4(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
   const int gs = sw(SW_GEMM3S);
   if (gs >= 0 ? gs != 0 : ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160))
     return launch_gemm3s(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);

@@ -1,0 +1,432 @@
+// bf16 GEMM with an optional K-extension, two wave groups in anti-phase (gfx950):
+//     C[M,N] = alpha * (A[M,K] . op(B) + A2[M,64] . op(B2)) + beta * C + bias[N]
+// Same contract as gemm2.hip (the dense-accumulator form of the SoW layer, tn_gradient/layer/sow.py:109-121 as ONE
+// fp32-accumulated product: y = [x, h] . [W_acc; B], dX = [dY, dh] . [W_acc^T; A^T]); a different main loop.
+//
+// Why another main loop.  gemm2 / gemm3 advance K in 32-wide stages with one barrier per stage and run at 36-50 % of the
+// matrix pipe: every wave loads, waits and multiplies in the same rhythm, so the pipe idles while the fragments and the
+// DMA issue go out.  Here (the structure of the CDNA guide's 256 x 256 "8-phase" template, rebuilt for this contract):
+//   * 256 x 256 tile, K in 64-wide tiles, 8 waves = 2 (rows) x 4 (columns), 128 x 64 per wave, v_mfma_f32_16x16x32_bf16
+//     (the chip holds a higher clock on it than on 32x32x16 at equal cycles per flop);
+//   * the two wave ROWS run one barrier apart: between two barriers one group issues its 16 MFMAs of a 64 x 32 quadrant
+//     while the other (its SIMD partners) reads the next quadrant's fragments and issues the DMA of one half-tile;
+//   * a K-tile lives in LDS as four 16-KiB half-tiles cut along the quadrant boundaries -- A0 / A1 = the first / second 64
+//     rows of BOTH wave rows, B0 / B1 = the first / second 32 columns of ALL FOUR wave columns -- so that a half-tile is
+//     read in exactly one phase of its K-tile and its slot can be re-filled two phases later: quadrant order (0,0) (0,1)
+//     (1,1) (1,0) reads A0 + B0, B1, A1, nothing; phase P issues the DMA of half-tile P + 6 (order A0 B0 B1 A1 per tile),
+//     2 x 64 KiB ring = 8 slots, up to 5 half-tiles (80 KiB) in flight per CU;
+//   * counted waits only: after its DMA issue every phase waits for vmcnt(8) = everything but the four youngest
+//     half-tiles, which is exactly what phase P + 1 reads; that wait is followed by two barriers before the read (the
+//     groups are one barrier apart);
+//   * k-contiguous half-tiles are [128][64] images (128-byte rows), 16-byte chunk c of row r at c ^ ((r >> 1) & 7):
+//     every ds_read_b128 lane group touches 16 distinct 16-byte slots; the k-major B of the forward product stays k-major
+//     ([64 k][128 n], 256-byte rows, chunk c of k-row k at c ^ (((k & 3) | ((k >> 3) & 1) << 2) << 1)) and is read
+//     with ds_read_b64_tr_b16.  The XOR sits on the per-lane SOURCE address (LDS-DMA writes lane-linearly);
+//   * the products are computed TRANSPOSED (the W fragment is the MFMA's A operand): a lane then holds 4 consecutive
+//     output columns of one token row, the epilogue parks 16 x 64 blocks in a wave-private LDS scratch with four
+//     16-byte writes and stores whole 128-byte row segments;
+//   * per-lane source pointers for the eight DMA instructions of a K-tile are carried in registers and advanced by one
+//     64-bit add; rows / columns beyond the matrix are CLAMPED (they only feed outputs that are never stored); the K tail
+//     and the extension tile take a checked path that reads the zero page where k is out of range.
+#include "kernels.hpp"
+#include "lds_dma.hpp"
+#include <type_traits>
+
+namespace sow {
+
+constexpr int G4_BM = 256, G4_BN = 256, G4_BK = 64;
+constexpr int G4_THREADS = 512;
+constexpr int G4_HALF = 128 * G4_BK * 2;   // 16 KiB
+constexpr int G4_BUF = 4 * G4_HALF;        // 64 KiB: A0 | A1 | B0 | B1
+constexpr int G4_LDS = 2 * G4_BUF;         // 128 KiB
+constexpr int G4_OFF_A0 = 0, G4_OFF_A1 = G4_HALF, G4_OFF_B0 = 2 * G4_HALF, G4_OFF_B1 = 3 * G4_HALF;
+constexpr int G4_SCR_LD = 68;              // floats per scratch row (64 + 4: 16-byte aligned rows, staggered banks)
+constexpr int G4_SCR = 16 * G4_SCR_LD * 4; // bytes of one wave's epilogue scratch
+
+struct Gemm4Params {
+  const bf16_t* A;
+  const bf16_t* B;
+  const bf16_t* A2;   // [M, 64] or nullptr
+  const bf16_t* B2;   // NT: [N, 64]; NN: [k2, N]
+  bf16_t* C;
+  const bf16_t* bias;
+  int64_t M, lda, ldb, lda2, ldb2, ldc;
+  int N, K, k2;
+  float alpha, beta;
+  int nt_store;
+};
+
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+}
+
+// LDS reads with compile-time immediate offsets (inline asm: invisible to hipcc's vmcnt bookkeeping, see lds_dma.hpp)
+template <int OFF> __device__ __forceinline__ void g4_rd128(u32x4& d, uint32_t a) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void g4_rdtr(u32x2& d, uint32_t a) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF) : "memory");
+}
+// x fragments of row half MH: 4 row tiles x 2 k-steps
+template <int MH> __device__ __forceinline__ void g4_read_a(u32x4 (&af)[4][2], uint32_t a0, uint32_t a1) {
+  g4_rd128<MH * G4_HALF + 0 * 2048>(af[0][0], a0);
+  g4_rd128<MH * G4_HALF + 0 * 2048>(af[0][1], a1);
+  g4_rd128<MH * G4_HALF + 1 * 2048>(af[1][0], a0);
+  g4_rd128<MH * G4_HALF + 1 * 2048>(af[1][1], a1);
+  g4_rd128<MH * G4_HALF + 2 * 2048>(af[2][0], a0);
+  g4_rd128<MH * G4_HALF + 2 * 2048>(af[2][1], a1);
+  g4_rd128<MH * G4_HALF + 3 * 2048>(af[3][0], a0);
+  g4_rd128<MH * G4_HALF + 3 * 2048>(af[3][1], a1);
+}
+// W fragments of column half NH from a k-contiguous image: 2 column tiles x 2 k-steps
+template <int NH> __device__ __forceinline__ void g4_read_b_nt(u32x4 (&bf)[2][2], uint32_t b0, uint32_t b1) {
+  g4_rd128<NH * G4_HALF + 0 * 2048>(bf[0][0], b0);
+  g4_rd128<NH * G4_HALF + 0 * 2048>(bf[0][1], b1);
+  g4_rd128<NH * G4_HALF + 1 * 2048>(bf[1][0], b0);
+  g4_rd128<NH * G4_HALF + 1 * 2048>(bf[1][1], b1);
+}
+// ... from a k-major image (transposed reads): [nt][ks] low / high k quads
+template <int NH> __device__ __forceinline__ void g4_read_b_nn(u32x2 (&bl)[2][2], u32x2 (&bh)[2][2], uint32_t n0a, uint32_t n1a) {
+  g4_rdtr<NH * G4_HALF + 0>(bl[0][0], n0a);
+  g4_rdtr<NH * G4_HALF + 1024>(bh[0][0], n0a);
+  g4_rdtr<NH * G4_HALF + 8192>(bl[0][1], n0a);
+  g4_rdtr<NH * G4_HALF + 8192 + 1024>(bh[0][1], n0a);
+  g4_rdtr<NH * G4_HALF + 0>(bl[1][0], n1a);
+  g4_rdtr<NH * G4_HALF + 1024>(bh[1][0], n1a);
+  g4_rdtr<NH * G4_HALF + 8192>(bl[1][1], n1a);
+  g4_rdtr<NH * G4_HALF + 8192 + 1024>(bh[1][1], n1a);
+}
+
+// kinds of half-tile, in DMA issue order within a K-tile
+enum : int { G4_A0 = 0, G4_B0 = 1, G4_B1 = 2, G4_A1 = 3 };
+template <int KIND> __device__ __forceinline__ constexpr int g4_slot_off() {
+  return KIND == G4_A0 ? G4_OFF_A0 : KIND == G4_A1 ? G4_OFF_A1 : KIND == G4_B0 ? G4_OFF_B0 : G4_OFF_B1;
+}
+
+template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(const Gemm4Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tiles_n = (p.N + G4_BN - 1) / G4_BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (int64_t)(lid / tiles_n) * G4_BM;
+  const int n0 = (lid % tiles_n) * G4_BN;
+  const int K = p.K, N = p.N;
+  const int64_t M = p.M;
+  const int nfull = K / G4_BK;
+  const int NTL = nfull + ((K % G4_BK) ? 1 : 0) + (p.A2 ? 1 : 0);   // K-tiles
+  const int H = 4 * NTL;                                            // half-tiles
+  const char* zp = zero_page_for(lane);
+
+  // ------------------------------------------------------------------ DMA geometry (per lane)
+  // k-contiguous image [128][64]: instruction ii of this wave covers image rows 16 w + 8 ii .. + 7
+  const int c_pc = lane & 7;                                    // physical chunk this lane writes
+  int c_lr[2], c_q[2];                                          // image row, logical chunk
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    c_lr[ii] = 16 * w + 8 * ii + (lane >> 3);
+    c_q[ii] = c_pc ^ ((c_lr[ii] >> 1) & 7);
+  }
+  auto a_row = [&](int mh, int lr) -> int64_t {                 // global row of image row lr of A half mh (clamped)
+    const int64_t gr = m0 + (lr >> 6) * 128 + mh * 64 + (lr & 63);
+    return gr < M ? gr : M - 1;
+  };
+  auto b_col_nt = [&](int nh, int lr) -> int {                  // global column of image row lr of B half nh (clamped)
+    const int gn = n0 + (lr >> 5) * 64 + nh * 32 + (lr & 31);
+    return gn < N ? gn : N - 1;
+  };
+  // k-major image [64 k][128 n]: instruction ii covers k rows 8 w + 4 ii .. + 3
+  const int m_kr0 = 8 * w + (lane >> 4);                        // k row of ii = 0 (ii = 1: + 4)
+  const int m_f = (((lane >> 4) & 3) | ((w & 1) << 2)) << 1;    // swizzle of that k row (the same for ii = 1)
+  const int m_q = (lane & 15) ^ m_f;                            // logical chunk
+  auto b_col_nn = [&](int nh) -> int {                          // first global column of this lane's chunk (clamped)
+    const int lc = 8 * m_q;
+    const int gn = n0 + (lc >> 5) * 64 + nh * 32 + (lc & 31);
+    return gn + 8 <= N ? gn : N - 8;
+  };
+
+  // per-lane source pointers of the full K-tiles, advanced per tile
+  const bf16_t* pA[2][2];
+  const bf16_t* pB[2][2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      pA[hh][ii] = p.A + a_row(hh, c_lr[ii]) * p.lda + 8 * c_q[ii];
+      if constexpr (NT) pB[hh][ii] = p.B + (int64_t)b_col_nt(hh, c_lr[ii]) * p.ldb + 8 * c_q[ii];
+      else pB[hh][ii] = p.B + (int64_t)(m_kr0 + 4 * ii) * p.ldb + b_col_nn(hh);
+    }
+  const int64_t stepB = NT ? (int64_t)G4_BK : (int64_t)G4_BK * p.ldb;
+
+  // DMA of half-tile KIND of K-tile `tile`
+  auto issue = [&](auto kind_c, int tile) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr bool IS_A = KIND == G4_A0 || KIND == G4_A1;
+    constexpr int HH = (KIND == G4_A1 || KIND == G4_B1) ? 1 : 0;
+    char* dst = smem + (tile & 1) * G4_BUF + g4_slot_off<KIND>() + (2 * w) * 1024;
+    if (tile < nfull) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        if constexpr (IS_A) {
+          dma16(pA[HH][ii], dst + ii * 1024);
+          pA[HH][ii] += G4_BK;
+        } else {
+          dma16(pB[HH][ii], dst + ii * 1024);
+          pB[HH][ii] += stepB;
+        }
+      }
+      return;
+    }
+    // checked path: the K tail of the main operands, or the extension tile
+    const bool ext = p.A2 != nullptr && tile == NTL - 1;
+    const int k0 = ext ? 0 : nfull * G4_BK;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const void* src;
+      if constexpr (IS_A) {
+        const bf16_t* base = ext ? p.A2 : p.A;
+        const int64_t ld = ext ? p.lda2 : p.lda;
+        const int klim = ext ? 64 : K;
+        const int kk = k0 + 8 * c_q[ii];
+        src = kk < klim ? (const void*)(base + a_row(HH, c_lr[ii]) * ld + kk) : (const void*)zp;
+      } else if constexpr (NT) {
+        const bf16_t* base = ext ? p.B2 : p.B;
+        const int64_t ld = ext ? p.ldb2 : p.ldb;
+        const int klim = ext ? 64 : K;
+        const int kk = k0 + 8 * c_q[ii];
+        src = kk < klim ? (const void*)(base + (int64_t)b_col_nt(HH, c_lr[ii]) * ld + kk) : (const void*)zp;
+      } else {
+        const bf16_t* base = ext ? p.B2 : p.B;
+        const int64_t ld = ext ? p.ldb2 : p.ldb;
+        const int krows = ext ? p.k2 : K;
+        const int gk = k0 + m_kr0 + 4 * ii;
+        src = gk < krows ? (const void*)(base + (int64_t)gk * ld + b_col_nn(HH)) : (const void*)zp;
+      }
+      dma16(src, dst + ii * 1024);
+    }
+  };
+  using KA0 = std::integral_constant<int, G4_A0>;
+  using KB0 = std::integral_constant<int, G4_B0>;
+  using KB1 = std::integral_constant<int, G4_B1>;
+  using KA1 = std::integral_constant<int, G4_A1>;
+
+  // ------------------------------------------------------------------ fragment addresses (per lane)
+  const uint32_t base = lds_addr(smem);
+  const int fsw = (r16 >> 1) & 7;
+  const int ch0 = (fsw & 4) | (g ^ (fsw & 3));                  // physical chunk of k-step 0 (k-step 1: ^ 4)
+  uint32_t a_off[2], b_off[2];                                  // [ks] (NT) / [nt] (NN); buffer bit toggled per K-tile
+  a_off[0] = base + (uint32_t)((wr * 64 + r16) * 128 + ch0 * 16);
+  a_off[1] = base + (uint32_t)((wr * 64 + r16) * 128 + (ch0 ^ 4) * 16);
+  if constexpr (NT) {
+    b_off[0] = base + (uint32_t)(G4_OFF_B0 + (wc * 32 + r16) * 128 + ch0 * 16);
+    b_off[1] = base + (uint32_t)(G4_OFF_B0 + (wc * 32 + r16) * 128 + (ch0 ^ 4) * 16);
+  } else {
+    const int qq = r16 >> 2, pp = r16 & 3;
+    const int f = (qq | ((g & 1) << 2)) << 1;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int chunk = wc * 4 + nt * 2 + (pp >> 1);
+      b_off[nt] = base + (uint32_t)(G4_OFF_B0 + (8 * g + qq) * 256 + ((chunk ^ f) * 16) + 8 * (pp & 1));
+    }
+  }
+
+  f32x4 acc[2][4][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 af[4][2];           // [mt][ks]      x fragments of the current row half
+  u32x4 bf[2][2][2];        // [nh][nt][ks]  W fragments of both column halves (k-contiguous image)
+  u32x2 bl[2][2][2], bh[2][2][2];   // the same from the k-major image: low / high four k of every fragment
+
+  auto read_a = [&](auto mh_c) { g4_read_a<decltype(mh_c)::value>(af, a_off[0], a_off[1]); };
+  auto read_b = [&](auto nh_c) {
+    constexpr int NH = decltype(nh_c)::value;
+    if constexpr (NT) g4_read_b_nt<NH>(bf[NH], b_off[0], b_off[1]);
+    else g4_read_b_nn<NH>(bl[NH], bh[NH], b_off[0], b_off[1]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // one phase of K-tile `tile`: fragment reads of the quadrant, DMA of half-tile P + 6, counted wait, barrier, 16 MFMAs, barrier
+  auto phase = [&](auto ph_c, auto tail_c, int tile) {
+    constexpr int PH = decltype(ph_c)::value;
+    constexpr bool TAIL = decltype(tail_c)::value;
+    constexpr int MH = PH >= 2 ? 1 : 0;
+    constexpr int NH = (PH == 1 || PH == 2) ? 1 : 0;
+    if constexpr (PH == 0) {
+      read_b(I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(I0{});
+    } else if constexpr (PH == 1) {
+      read_b(I1{});
+    } else if constexpr (PH == 2) {
+      read_a(I1{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int P = 4 * tile + PH;
+    const int h = P + 6;
+    if (!TAIL || h < H) {
+      if constexpr (PH == 0) issue(KB1{}, h >> 2);
+      else if constexpr (PH == 1) issue(KA1{}, h >> 2);
+      else if constexpr (PH == 2) issue(KA0{}, h >> 2);
+      else issue(KB0{}, h >> 2);
+    }
+    if constexpr (!TAIL) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      int newer = H - 3 - P;
+      newer = newer < 0 ? 0 : (newer > 4 ? 4 : newer);
+      wait_groups<2>(newer);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          u32x4 wf;
+          if constexpr (NT) wf = bf[NH][nt][ks];
+          else wf = join2(bl[NH][nt][ks], bh[NH][nt][ks]);
+          acc[MH][mt][NH][nt] = mfma16(wf, af[mt][ks], acc[MH][mt][NH][nt]);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PH == 3) {   // next K-tile: the other buffer
+      a_off[0] ^= G4_BUF, a_off[1] ^= G4_BUF, b_off[0] ^= G4_BUF, b_off[1] ^= G4_BUF;
+    }
+  };
+  using T0 = std::integral_constant<bool, false>;
+  using T1 = std::integral_constant<bool, true>;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+
+  // ------------------------------------------------------------------ prologue: half-tiles 0 .. 5
+  issue(KA0{}, 0), issue(KB0{}, 0), issue(KB1{}, 0), issue(KA1{}, 0);
+  if (NTL > 1) issue(KA0{}, 1), issue(KB0{}, 1);
+  wait_groups<2>(NTL > 1 ? 4 : 2);     // A0, B0 of K-tile 0 have landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();        // ... everyone's
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
+  __builtin_amdgcn_sched_barrier(0);
+
+  int tile = 0;
+#pragma unroll 1
+  for (; tile < NTL - 2; ++tile) {
+    phase(P0{}, T0{}, tile);
+    phase(P1{}, T0{}, tile);
+    phase(P2{}, T0{}, tile);
+    phase(P3{}, T0{}, tile);
+  }
+#pragma unroll 1
+  for (; tile < NTL; ++tile) {
+    phase(P0{}, T1{}, tile);
+    phase(P1{}, T1{}, tile);
+    phase(P2{}, T1{}, tile);
+    phase(P3{}, T1{}, tile);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // catch up: every wave has passed its last fragment read
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ------------------------------------------------------------------ epilogue
+  // acc[mh][mt][nh][nt][j] = C[row = 128 wr + 64 mh + 16 mt + r16][col = 64 wc + 32 nh + 16 nt + 4 g + j]
+  float* sc = (float*)(smem + w * G4_SCR);
+  const bool nts = p.nt_store != 0;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) *(f32x4*)(sc + r16 * G4_SCR_LD + nh * 32 + nt * 16 + 4 * g) = acc[mh][mt][nh][nt];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const int64_t grow = m0 + wr * 128 + mh * 64 + mt * 16 + r;
+        const int gcol = n0 + wc * 64 + c;
+        if (grow < M && gcol < N) {
+          float v[8];
+          const f32x4 t0 = *(const f32x4*)(sc + r * G4_SCR_LD + c), t1 = *(const f32x4*)(sc + r * G4_SCR_LD + c + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = t0[j] * p.alpha, v[4 + j] = t1[j] * p.alpha;
+          bf16_t* dst = p.C + grow * p.ldc + gcol;
+          if (p.beta != 0.f) {
+            const u32x4 old = *(const u32x4*)dst;
+            const bf16_t* o = (const bf16_t*)&old;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += p.beta * (float)o[j];
+          }
+          if (p.bias) {
+            const u32x4 bv = *(const u32x4*)(p.bias + gcol);
+            const bf16_t* b = (const bf16_t*)&bv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+          }
+          u32x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+          if (nts) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(pk) : "memory");
+          else *(u32x4*)dst = pk;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool g4_al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                     const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                     int dtype) {
+  if (dtype != SOW_BF16 || !A || !B || !C) return false;
+  if (M < 1 || N < 64 || K < 64) return false;
+  if (K % 8 || N % 8 || lda % 8 || ldb % 8 || ldc % 8) return false;
+  if (!g4_al16(A) || !g4_al16(B) || !g4_al16(C) || (bias && !g4_al16(bias))) return false;
+  if (A2 && (!B2 || lda2 % 8 || ldb2 % 8 || !g4_al16(A2) || !g4_al16(B2))) return false;
+  (void)nt;
+  return true;
+}
+
+int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                 const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                 float alpha, float beta, hipStream_t stream) {
+  Gemm4Params p;
+  p.A = (const bf16_t*)A, p.B = (const bf16_t*)B, p.A2 = (const bf16_t*)A2, p.B2 = (const bf16_t*)B2;
+  p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias;
+  p.M = M, p.lda = lda, p.ldb = ldb, p.lda2 = lda2, p.ldb2 = ldb2, p.ldc = ldc;
+  p.N = N, p.K = K, p.k2 = k2 < 64 ? k2 : 64;
+  p.alpha = alpha, p.beta = beta;
+  p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
+  const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
+  if (tiles <= 0) return SOW_OK;
+  if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+  if (nt) {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<true>);
+    hipLaunchKernelGGL(gemm4_kernel<true>, dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+  } else {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<false>);
+    hipLaunchKernelGGL(gemm4_kernel<false>, dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+  }
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+}  // namespace sow

@@ -142,6 +142,13 @@ int launch_pad64(const void* in, void* out, int rows, int r, hipStream_t stream)
 int launch_gemm3(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                  float alpha, float beta, hipStream_t stream);
+// gemm4.hip (same contract as launch_gemm2; 256x256x64 tiles, two wave groups in anti-phase, v_mfma_f32_16x16x32_bf16)
+bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                     const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                     int dtype);
+int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
+                 const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
+                 float alpha, float beta, hipStream_t stream);
 // gemm2h.hip (the same product with the projection h = hscale * X . op(F) computed in the kernel: one launch per pass)
 bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
                       const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,

@@ -487,7 +487,7 @@ def test_gemm(dtype, ta, tb):
         assert rel_err(out.float().cpu(), ref) < (TOL if dtype == torch.float32 else 2e-2), (M, N, K)
 
 
-@pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave", "small"])
+@pytest.mark.parametrize("kernel", ["auto", "8wave", "1wave", "small", "gemm4"])
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_streaming_bf16(tb, kernel):
     """bf16 products with >= 160 tiles of 256x256 take the LDS-DMA streaming kernels (gemm2: 8 waves, K < 2048; gemm3: one
@@ -495,9 +495,11 @@ def test_gemm_streaming_bf16(tb, kernel):
     and 32, one- and two-stage K, alpha / beta / bias epilogue."""
     from sow_amd import _lib, ops
     if kernel == "small":
-        sel = dict(GEMM3S=1)                                  # 128x128-tile kernel (gemm3s) on every shape
+        sel = dict(GEMM4=0, GEMM3S=1)                         # 128x128-tile kernel (gemm3s) on every shape
+    elif kernel == "gemm4":
+        sel = dict(GEMM4=1)                                   # anti-phase wave groups, 64-wide K-tiles (gemm4) on every shape
     elif kernel != "auto":
-        sel = dict(GEMM3S=0, GEMM3=1 if kernel == "1wave" else 0)
+        sel = dict(GEMM4=0, GEMM3S=0, GEMM3=1 if kernel == "1wave" else 0)
     else:
         sel = {}
     gen = torch.Generator().manual_seed(5)
@@ -513,7 +515,7 @@ def test_gemm_streaming_bf16(tb, kernel):
             ref0 = a.float() @ (b.float().t() if tb else b.float())
             out0 = ops.gemm(a.to(DEV), b.to(DEV), trans_b=tb)
             assert rel_err(out0.float().cpu(), ref0) < 1e-2, (M, N, K)
-    assert _lib.load().sow_get_switch(b"GEMM3S") == -1 and _lib.load().sow_get_switch(b"GEMM3") == -1
+    assert all(_lib.load().sow_get_switch(k) == -1 for k in (b"GEMM3S", b"GEMM3", b"GEMM4"))
 
 
 def test_zero_state_and_reset_optimizer():
