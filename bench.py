@@ -340,7 +340,7 @@ def train_mode(args, world, rank, device, steps=None, warmup=None, quiet=False):
     trainable = [p for p in model.parameters() if p.requires_grad and id(p) not in ids]
     fused = args.fused_factors
     grouped = 0
-    if not args.no_group_siblings and not fused:      # (layers attached to a FactorBucket keep their own backward)
+    if not args.no_group_siblings:    # composes with --fused-factors: grouped data-gradient launch, block-level weight gradients
         from sow_amd import group_siblings
         grouped = group_siblings(model)
     inner = model
@@ -796,7 +796,9 @@ def main():
                                     "whichever pipe the products run on"}
         out["northstar"] = northstar(device)
         try:
-            t = train_mode(args, 1, 0, device, steps=max(3, min(args.steps, 10)), warmup=3, quiet=True)
+            targs = argparse.Namespace(**vars(args))
+            targs.fused_factors = True     # FactorBucket path: block-level row-owner weight gradients, one fused AdamW kernel
+            t = train_mode(targs, 1, 0, device, steps=max(3, min(args.steps, 10)), warmup=3, quiet=True)
             out["train"] = {"what": t["config"]["workload"], "ms_per_step": t["ms_per_step"], "tokens_per_s": t["value"],
                             "fused_factors": t["config"]["fused_factors"], "sibling_groups": t["config"]["sibling_groups"]}
         except Exception as e:  # transformers missing or too old on the box: the headline must still print

@@ -35,15 +35,30 @@ def factor_parameters(model: nn.Module) -> List[nn.Parameter]:
     return out
 
 
-class _GradSink:
-    """Per-layer hook used by SoWLinear's autograd backward after FactorBucket.attach(): runs the data gradient and the
-    token-slab partial sums of the weight gradients (own persistent workspace), accumulating into the layer's views of
-    the flat gradient buffer, and registers the layer with the bucket's deferred reduction."""
+def _block_key(name: str) -> str:
+    """Decoder-block prefix of a module name: everything up to the last numeric path component that is not the leaf
+    (`model.layers.3.self_attn.q_proj` -> `model.layers.3`, `encoder.layer.7.attention.output.dense` -> `encoder.layer.7`);
+    modules outside such a container share their parent's name."""
+    parts = name.split(".")
+    for i in range(len(parts) - 2, -1, -1):
+        if parts[i].isdigit():
+            return ".".join(parts[:i + 1])
+    return ".".join(parts[:-1])
 
-    def __init__(self, bucket, pA, pB):
-        self.bucket, self.pA, self.pB = bucket, pA, pB
+
+class _GradSink:
+    """Per-layer hook used by SoWLinear's autograd backward after FactorBucket.attach(): runs the data gradient right away
+    (dX is what the previous layer's backward waits for) and queues the layer's weight gradients with its decoder block.
+    When every attached layer of the block has reported in, the block's token-slab partial sums run as ONE grouped launch
+    (sow_backward_group: the row-owner kernel with slab counts planned over the block, the headline path of bench.py),
+    accumulating into the layers' views of the flat gradient buffer; the reductions of all blocks are deferred to
+    FactorBucket.finalize()."""
+
+    def __init__(self, bucket, pA, pB, block=""):
+        self.bucket, self.pA, self.pB, self.block = bucket, pA, pB, block
         self.ws = None
-        self.pending = False
+        self.pending = False      # partial sums launched, reduction not yet run
+        self.queued = False       # data gradient done, waiting for the rest of the block
 
     def usable(self, A, B) -> bool:
         # n_iter == 1 layers only (A, B ARE the bucket's parameters), gradients bound to the flat buffer, r <= 64
@@ -52,8 +67,12 @@ class _GradSink:
                 and pA.grad is not None and pB.grad is not None
                 and pA.grad.data_ptr() == self.bucket.grad_ptr(pA) and pB.grad.data_ptr() == self.bucket.grad_ptr(pB))
 
-    def backward(self, dy2, x2, h, A, B, acc_down, acc_up, scale):
+    def prepare(self, x2, B, acc_down, acc_up):
+        """Checks and workspace of one backward pass through this layer; returns (acc_kind, r_acc)."""
         from . import _lib, ops
+        self.bucket._refuse_backward_during_collective()     # before anything is added to an already reduced buffer
+        if self.queued:              # the same layer again before its block was complete (shared module, checkpoint replay)
+            self.bucket._flush_block(self.block)
         if self.pending:             # second backward through this layer before finalize(): its partials are still needed
             self.bucket.finalize()
         T, d_in = x2.shape
@@ -63,13 +82,22 @@ class _GradSink:
         need = ops.workspace_bytes(T, d_in, d_out, r, r_acc, kind, x2.dtype) + 256
         if self.ws is None or self.ws.numel() < need or self.ws.device != x2.device:
             self.ws = torch.empty(need, dtype=torch.uint8, device=x2.device)
+        return kind, r_acc
+
+    def queue(self, dy2, x2, h, A, B, acc_down, acc_up, scale, kind, r_acc):
+        """The data gradient of this pass has been enqueued (dh is in self.ws): hand the weight gradients to the block."""
+        from . import _lib
+        self.bucket._block_add(self, (dy2, x2, h, A, B, acc_down if kind != _lib.ACC_NONE else None,
+                                      acc_up if kind == _lib.ACC_LOWRANK else None, float(scale), kind, r_acc))
+
+    def backward(self, dy2, x2, h, A, B, acc_down, acc_up, scale):
+        from . import _lib, ops
+        kind, r_acc = self.prepare(x2, B, acc_down, acc_up)
         out = (self.pA.grad, self.pB.grad, None)
+        dy2 = dy2.contiguous()
         dx, _, _, _ = ops.sow_backward(dy2, x2, h, A, B, acc_down, acc_up, scale, False, out=out, grad_beta=1.0,
-                                       phases=_lib.BWD_DATA | _lib.BWD_WEIGHTS_PARTIAL, workspace=self.ws)
-        self.bucket._reducer.add(x2, B, out, 1.0, self.ws, acc_down, acc_up)
-        self.bucket._sinks_pending.append(self)
-        self.pending = True
-        self.bucket._layer_done()
+                                       phases=_lib.BWD_DATA, workspace=self.ws)
+        self.queue(dy2, x2, h, A, B, acc_down, acc_up, scale, kind, r_acc)
         return dx
 
 
@@ -102,6 +130,7 @@ class FactorBucket:
         self._armed = True
         self._reducer = None
         self._sinks_pending: list = []
+        self._blocks: dict = {}          # decoder-block key -> {"n": attached layers, "queue": [(sink, record)]}
         self._off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
         self._n_attached = 0
         self._arrived = 0
@@ -140,11 +169,14 @@ class FactorBucket:
             self._reducer = ops.DeferredReduce()
         mine = {id(p) for p in self.params}
         n = 0
-        for _, m in model.named_modules():
+        self._blocks = {}
+        for name, m in model.named_modules():
             if isinstance(m, SoWLinear) and m.n_iter == 1 and m.bias is None:
                 pA, pB = m.downscale_weights._parameters["0"], m.upscale_weights._parameters["0"]
                 if id(pA) in mine and id(pB) in mine:
-                    m._grad_sink = _GradSink(self, pA, pB)
+                    key = _block_key(name)
+                    m._grad_sink = _GradSink(self, pA, pB, key)
+                    self._blocks.setdefault(key, {"n": 0, "queue": []})["n"] += 1
                     n += 1
         self._n_attached = n
         self._auto, self._auto_group = bool(auto_all_reduce), group
@@ -179,18 +211,70 @@ class FactorBucket:
 
         return _NoSync()
 
-    def _layer_done(self) -> None:
+    def _refuse_backward_during_collective(self) -> None:
         if self._works:
             raise RuntimeError("FactorBucket: a backward pass reached an attached layer while the bucket's all-reduce is "
                                "pending -- its gradients would be added on top of an already reduced buffer.  With gradient "
                                "accumulation run the non-final micro-batches under `with bucket.no_sync():`; call wait() "
                                "before the next armed backward")
+
+    def _layer_done(self) -> None:
+        self._refuse_backward_during_collective()
         self._arrived += 1
         if self._auto and self._armed and self._n_attached and self._arrived % self._n_attached == 0:
             self.all_reduce_async(group=self._auto_group)
 
+    # ------------------------------------------------------------------ block-level weight gradients
+    def _block_add(self, sink, rec) -> None:
+        blk = self._blocks.setdefault(sink.block, {"n": 1, "queue": []})
+        blk["queue"].append((sink, rec))
+        sink.queued = True
+        if len(blk["queue"]) >= blk["n"]:
+            self._flush_block(sink.block)
+        self._layer_done()
+
+    def _flush_block(self, key) -> None:
+        """ONE grouped launch of the weight-gradient partial sums of the layers queued for decoder block `key`
+        (reference: the seven SoWLinear backward passes of an HF decoder block, sow.py:107-126 under autograd)."""
+        from . import _lib, ops
+        blk = self._blocks.get(key)
+        if not blk or not blk["queue"]:
+            return
+        q, blk["queue"] = blk["queue"], []
+        # layers of one dtype / device go together (a model holds one of each; anything else flushes in runs)
+        while q:
+            dt, dev = q[0][1][1].dtype, q[0][1][1].device
+            run = [e for e in q if e[1][1].dtype == dt and e[1][1].device == dev]
+            q = [e for e in q if not (e[1][1].dtype == dt and e[1][1].device == dev)]
+            arr = (_lib.LayerArgs * len(run))()
+            stable = []
+            for i, (sink, (dy2, x2, h, A, B, acc_down, acc_up, scale, kind, r_acc)) in enumerate(run):
+                T, d_in = x2.shape
+                r, d_out = B.shape
+                a = arr[i]
+                a.x, a.A, a.B = x2.data_ptr(), A.data_ptr(), B.data_ptr()
+                a.acc_down = acc_down.data_ptr() if acc_down is not None else None
+                a.acc_up = acc_up.data_ptr() if acc_up is not None else None
+                a.bias, a.y, a.h_save, a.dy, a.dx = None, dy2.data_ptr(), h.data_ptr(), dy2.data_ptr(), x2.data_ptr()
+                a.dA, a.dB, a.dbias = sink.pA.grad.data_ptr(), sink.pB.grad.data_ptr(), None
+                a.T, a.d_in, a.d_out, a.r_live, a.r_acc, a.acc_kind = T, d_in, d_out, r, r_acc, kind
+                a.scale, a.grad_beta = scale, 1.0
+                a.workspace, a.workspace_bytes = sink.ws.data_ptr(), sink.ws.numel()
+                stable.append((a.dA, a.dB, a.workspace, T, d_in, d_out, r, r_acc, kind))
+            group = ops.LayerGroup.from_args(arr, len(run), ops._dt(run[0][1][1]), dev, keep=run)
+            phases = _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS
+            group.backward(phases)
+            self._reducer.add_group(group, phases, stable_key=tuple(stable))
+            for sink, _ in run:
+                sink.queued, sink.pending = False, True
+                self._sinks_pending.append(sink)
+
     def finalize(self) -> None:
-        """Sum the pending slab partials of every attached layer (no-op when nothing is pending)."""
+        """Launch the weight gradients of incomplete blocks (layers that did not all run backward) and sum the pending
+        slab partials of every attached layer (no-op when nothing is pending)."""
+        for key, blk in self._blocks.items():
+            if blk["queue"]:
+                self._flush_block(key)
         if self._reducer is not None and self._sinks_pending:
             self._reducer.run()
             for s in self._sinks_pending:

@@ -28,8 +28,9 @@ class _SoWGroupFunction(torch.autograd.Function):
     """y_i = SoWLinear_i(x) for n layers on one input.  Tensor arguments per layer: A, B, acc_down, acc_up, bias."""
 
     @staticmethod
-    def forward(ctx, x, scales, *tensors):
+    def forward(ctx, x, scales, sinks, *tensors):
         n = len(scales)
+        ctx.sinks = sinks
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         per = [tensors[5 * i:5 * i + 5] for i in range(n)]
@@ -52,6 +53,30 @@ class _SoWGroupFunction(torch.autograd.Function):
         n = ctx.n
         saved = ctx.saved_tensors
         x2, hs, tensors = saved[0], saved[1:1 + n], saved[1 + n:]
+        sinks = ctx.sinks
+        if sinks is not None and x2.shape[0] > 0 and all(
+                s.usable(tensors[5 * i], tensors[5 * i + 1]) and tensors[5 * i + 4] is None for i, s in enumerate(sinks)):
+            # FactorBucket.attach(): ONE data-gradient launch for the siblings, weight gradients queued with their decoder
+            # block (dp._GradSink); autograd gets None for the factors
+            calls, recs = [], []
+            for i, sink in enumerate(sinks):
+                A, B, acc_down, acc_up, _ = tensors[5 * i:5 * i + 5]
+                kind, r_acc = sink.prepare(x2, B, acc_down, acc_up)
+                T, d_out = x2.shape[0], B.shape[1]
+                dy = dys[i]
+                dy2 = (torch.zeros(T, d_out, dtype=x2.dtype, device=x2.device) if dy is None else dy.reshape(-1, d_out).contiguous())
+                calls.append(ops.LayerCall(x2, A, B, acc_down=acc_down if kind != _lib.ACC_NONE else None,
+                                           acc_up=acc_up if kind == _lib.ACC_LOWRANK else None, scale=ctx.scales[i], h=hs[i],
+                                           dy2=dy2, dx=torch.empty_like(x2), out=(sink.pA.grad, sink.pB.grad, None),
+                                           grad_beta=1.0, y=dy2, workspace=sink.ws))
+                recs.append((sink, dy2, A, B, acc_down, acc_up, kind, r_acc))
+            ops.LayerGroup(calls).backward(_lib.BWD_DATA)
+            for i, (sink, dy2, A, B, acc_down, acc_up, kind, r_acc) in enumerate(recs):
+                sink.queue(dy2, x2, hs[i], A, B, acc_down, acc_up, ctx.scales[i], kind, r_acc)
+            dx = calls[-1].dx
+            for c in reversed(calls[:-1]):
+                dx = dx + c.dx
+            return (dx.reshape(ctx.x_shape), None, None, *([None] * (5 * n)))
         calls, outs = [], []
         for i in range(n):
             A, B, acc_down, acc_up, bias = tensors[5 * i:5 * i + 5]
@@ -77,7 +102,7 @@ class _SoWGroupFunction(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = []
         for (dA, dB, dbias) in outs:
             grads += [dA, dB, None, None, dbias]
-        return (dx.reshape(ctx.x_shape), None, *grads)
+        return (dx.reshape(ctx.x_shape), None, None, *grads)
 
 
 class SiblingGroup:
@@ -92,8 +117,11 @@ class SiblingGroup:
     def usable(self, x: torch.Tensor) -> bool:
         if not x.is_cuda or x.dtype not in ops._DT:
             return False
+        sinks = [getattr(m, "_grad_sink", None) for m in self.layers]
+        if any(s is not None for s in sinks) and not all(s is not None for s in sinks):
+            return False           # some siblings attached to a FactorBucket, some not: every layer runs on its own
         for m in self.layers:
-            if m.n_iter != 1 or getattr(m, "_grad_sink", None) is not None or m.downscale_weights[0].dtype != x.dtype:
+            if m.n_iter != 1 or m.downscale_weights[0].dtype != x.dtype:
                 return False
             # an accumulator the grouped launch cannot take as it stands (dtype / shape / device of a checkpoint that was
             # loaded in another precision, load_sow): the layer runs on its own and raises exactly what the ungrouped
@@ -117,7 +145,9 @@ class SiblingGroup:
         for m in self.layers:
             tensors += [m.downscale_weights._parameters["0"], m.upscale_weights._parameters["0"], m.acc_downweight,
                         m.acc_upweight, m.bias]
-        ys = _SoWGroupFunction.apply(x, tuple(float(m.scale) for m in self.layers), *tensors)
+        sinks = tuple(getattr(m, "_grad_sink", None) for m in self.layers)
+        ys = _SoWGroupFunction.apply(x, tuple(float(m.scale) for m in self.layers), sinks if sinks[0] is not None else None,
+                                     *tensors)
         self._key, self._x = key, x
         self._parked = {id(m): y for m, y in zip(self.layers, ys) if m is not layer}
         return ys[self.layers.index(layer)]

@@ -260,6 +260,14 @@ class LayerGroup:
         self.arr = (_lib.LayerArgs * len(calls))(*[c.args for c in calls])
         self.dtype, self.device = calls[0].dtype, calls[0].device
 
+    @classmethod
+    def from_args(cls, arr, n: int, dtype: int, device, keep=None) -> "LayerGroup":
+        """A group over a ready-made sow_layer_args array (the caller has validated the tensors and keeps them alive --
+        `keep` -- until the launches that read the raw pointers have been enqueued)."""
+        g = cls.__new__(cls)
+        g.calls, g.arr, g.dtype, g.device, g._keep = [None] * n, arr, dtype, device, keep
+        return g
+
     def forward(self) -> None:
         _launch(self.device, "sow_forward_group", _lib.load().sow_forward_group, self.arr, len(self.calls), self.dtype)
 
@@ -328,10 +336,13 @@ class DeferredReduce:
         self._blocks.append(nb.value)
         self._dev, self._dt = x2.device, _dt(x2)
 
-    def add_group(self, group: "LayerGroup", phases: int):
-        """Register (or re-validate) every layer of a group whose PARTIAL phase was just enqueued with `phases`."""
+    def add_group(self, group: "LayerGroup", phases: int, stable_key=None):
+        """Register (or re-validate) every layer of a group whose PARTIAL phase was just enqueued with `phases`.
+        `stable_key`: what the reduction descriptors of the group depend on (gradient buffers, workspaces, shapes) when the
+        group object and its activation pointers change from step to step -- the cached descriptors are then reused."""
         n = len(group.calls)
-        key = ("group", id(group), int(phases), bytes(group.arr))
+        key = (("group", int(phases), stable_key) if stable_key is not None
+               else ("group", id(group), int(phases), bytes(group.arr)))
         i = self._pos
         self._pos += n
         if i + n <= len(self._keys) and all(self._keys[i + k] == (key, k) for k in range(n)):

@@ -32,7 +32,8 @@ def _layer(d_in, d_out, r, dtype, bias=False, dense=False, seed=0):
 @pytest.mark.parametrize("dense", [False, True])
 def test_forward_without_saved_projection_is_bit_identical(shape, dtype, dense):
     """torch.no_grad() callers (eval / generate of scripts/commonsense_evaluate.py:268-287, the first pass of activation
-    checkpointing) run sow_forward with h_save = NULL: same y bit for bit as the training forward, and the oracle's."""
+    checkpointing) run sow_forward with h_save = NULL: same y as the training forward (bit for bit on the streaming path),
+    and the oracle's."""
     T, d_in, d_out, r = shape
     m = _layer(d_in, d_out, r, dtype, bias=True, dense=dense)
     x = torch.randn(T, d_in, device=DEV).to(dtype)
@@ -44,8 +45,12 @@ def test_forward_without_saved_projection_is_bit_identical(shape, dtype, dense):
         # with a dense accumulator and no h_save the low-rank term is added by a second kernel (one more rounding in bf16)
         tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
         assert rel_err(y_eval.float().cpu(), y_train.float().cpu()) < tol
-    else:
+    elif T > 8192 or T < 128:
         assert torch.equal(y_eval, y_train)
+    else:
+        # short inputs: with a saved projection the chain is split over K (fp32 partial sums + h_reduce), without it
+        # the unsplit kernel runs -- a different summation order, same value to fp32 / bf16 rounding
+        assert rel_err(y_eval.float().cpu(), y_train.float().cpu()) < (1e-2 if dtype == torch.bfloat16 else 1e-6)
     acc = m.acc_downweight.data.float().cpu() if dense else None
     y_ref = O.sow_forward(x.float().cpu(), [m.downscale_weights[0].data.float().cpu()], [m.upscale_weights[0].data.float().cpu()],
                           acc, None, 1.0, m.bias.data.float().cpu())
@@ -141,3 +146,140 @@ def test_factor_adamw_steps_with_the_lr_a_scheduler_wrote():
         assert opt.state_dict()["lr"] == step_lr
     for p, q in zip(ps, ref):
         assert rel_err(p.data.cpu(), q.data.cpu()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# block-level weight gradients from the module surface (verdict r2 item 4) and the bench's launch sequence (item 7)
+# ---------------------------------------------------------------------------------------------------------------
+class _Block(nn.Module):
+    """The seven projections of a llama decoder block with HF's attribute names and a data flow that uses all of them."""
+
+    def __init__(self, make, h=512, inter=1376):
+        super().__init__()
+        self.self_attn = nn.Module()
+        self.mlp = nn.Module()
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            setattr(self.self_attn, n, make(h, h))
+        self.mlp.gate_proj, self.mlp.up_proj, self.mlp.down_proj = make(h, inter), make(h, inter), make(inter, h)
+
+    def forward(self, x):
+        a = self.self_attn
+        x = x + a.o_proj(torch.tanh(a.q_proj(x)) * torch.tanh(a.k_proj(x)) + a.v_proj(x))
+        m = self.mlp
+        return x + m.down_proj(torch.tanh(m.gate_proj(x)) * m.up_proj(x))
+
+
+class _Tiny(nn.Module):
+    def __init__(self, make, nblk=2):
+        super().__init__()
+        self.layers = nn.ModuleList([_Block(make) for _ in range(nblk)])
+
+    def forward(self, x):
+        for b in self.layers:
+            x = b(x)
+        return x
+
+
+def test_block_level_weight_gradients_from_modules_vs_oracle():
+    """FactorBucket.attach() on a 2-block llama-shaped stack (r = 50, bf16, T = 8192): every layer's backward runs its data
+    gradient at once and the SEVEN weight-gradient jobs of a decoder block go out as one row-owner launch (the plan is
+    checked through sow_backward_group_plan).  The factor gradients are compared with the CPU ORACLE run on the same
+    (bf16-rounded) weights and inputs through the same data flow -- not with the per-layer HIP path."""
+    import ctypes
+
+    from oracle_backend import OracleSoWLinear
+    from sow_amd import SoWLinear, _lib
+    from sow_amd.dp import FactorBucket, factor_parameters
+    T, r = 8192, 50
+    torch.manual_seed(11)
+
+    def make_gpu(i, o):
+        m = SoWLinear(i, o, bias=False, rank=r, init_method="normal", device=DEV, dtype=torch.bfloat16)
+        nn.init.normal_(m.downscale_weights[0], std=0.04)
+        nn.init.normal_(m.upscale_weights[0], std=0.04)
+        return m
+
+    net = _Tiny(make_gpu)
+    ref = _Tiny(lambda i, o: OracleSoWLinear(i, o, False, r, 1.0, "normal"))
+    for (_, a), (_, b) in zip(net.named_modules(), ref.named_modules()):
+        if isinstance(a, SoWLinear):
+            b.downscale_weights[0].data = a.downscale_weights[0].data.float().cpu()
+            b.upscale_weights[0].data = a.upscale_weights[0].data.float().cpu()
+    x = (torch.randn(T, 512) * 0.5).bfloat16()
+    bucket = FactorBucket(factor_parameters(net))
+    assert bucket.attach(net) == 14 and sorted(bucket._blocks) == ["layers.0", "layers.1"]
+    assert all(b["n"] == 7 for b in bucket._blocks.values())
+    bucket.zero_grad()
+    net(x.to(DEV)).float().square().mean().backward()
+    assert not any(b["queue"] for b in bucket._blocks.values())       # both blocks went out complete, from backward
+    assert len(bucket._sinks_pending) == 14
+    bucket.finalize()
+    torch.cuda.synchronize()
+    ref(x.float()).square().mean().backward()
+    for (n, a), (_, b) in zip(net.named_modules(), ref.named_modules()):
+        if isinstance(a, SoWLinear):
+            for pa, pb in ((a.downscale_weights[0], b.downscale_weights[0]), (a.upscale_weights[0], b.upscale_weights[0])):
+                assert rel_err(pa.grad.float().cpu(), pb.grad) < 4e-2, n
+    # the plan the block launch took: one resident round of the row-owner kernel
+    lib = _lib.load()
+    fake = 1 << 20
+    arr = (_lib.LayerArgs * 7)()
+    for i, (di, do) in enumerate([(512, 512)] * 4 + [(512, 1376)] * 2 + [(1376, 512)]):
+        ws = lib.sow_workspace_bytes(T, di, do, r, 0, 0, _lib.BF16)
+        arr[i] = _lib.LayerArgs(x=fake, A=fake, B=fake, y=fake, h_save=fake, dy=fake, dx=fake, dA=fake, dB=fake, T=T, d_in=di,
+                                d_out=do, r_live=r, r_acc=0, acc_kind=0, scale=1.0, grad_beta=1.0, workspace=fake,
+                                workspace_bytes=ws + 256)
+    assert lib.sow_backward_group_plan(arr, 7, _lib.BF16, _lib.BWD_WEIGHTS_PARTIAL | _lib.BWD_GROUP_SLABS,
+                                       (ctypes.c_int * 14)()) == 1
+    # sibling groups compose with the bucket: q/k/v and gate/up run ONE forward and ONE data-gradient launch each, the weight
+    # gradients still go out per decoder block
+    from sow_amd import group_siblings, ungroup_siblings
+    g0 = [p.grad.clone() for p in bucket.params]
+    bucket.zero_grad()
+    assert group_siblings(net) == 4
+    net(x.to(DEV)).float().square().mean().backward()
+    assert not any(b["queue"] for b in bucket._blocks.values()) and len(bucket._sinks_pending) == 14
+    bucket.finalize()
+    torch.cuda.synchronize()
+    ungroup_siblings(net)
+    for p, g in zip(bucket.params, g0):
+        assert rel_err(p.grad.float().cpu(), g.float().cpu()) < 2e-2
+    # gradient accumulation: a second backward adds up (the sinks finalize their pending partials first)
+    g1 = [p.grad.clone() for p in bucket.params]
+    net(x.to(DEV)).float().square().mean().backward()
+    bucket.finalize()
+    torch.cuda.synchronize()
+    for p, g in zip(bucket.params, g1):
+        assert rel_err(p.grad.float().cpu(), 2 * g.float().cpu()) < 2e-2
+
+
+def test_bench_launch_sequence_vs_oracle():
+    """bench.py's exact per-block sequence at the full T = 32768 -- grouped forward {q,k,v} {o} {gate,up} {down}, grouped
+    data gradients in reverse, ONE block-level row-owner launch with BWD_GROUP_SLABS, DeferredReduce -- on one decoder block
+    of llama_60m shapes (r = 50, bf16).  y, dX (sampled rows) and dA / dB (whole) against the CPU oracle in fp32 on the same
+    bf16 inputs: tolerance 2e-2 of the largest reference magnitude (bf16 outputs, 32768-term sums)."""
+    import importlib.util
+    import os
+    import sys
+
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["bench_mod"] = bench
+    spec.loader.exec_module(bench)
+    T, r = 32768, 50
+    shapes = bench.layer_shapes()[:7]
+    stack = bench.Stack(shapes, T, r, torch.bfloat16, torch.device(DEV), "none")
+    stack.step()
+    torch.cuda.synchronize()
+    rows = torch.arange(0, T, 997)
+    for li, (di, do) in enumerate(shapes):
+        x, dy = stack.x[li].float().cpu(), stack.dy[li].float().cpu()
+        A, B = stack.A[li].data.float().cpu(), stack.B[li].data.float().cpu()
+        y_ref = O.sow_forward(x[rows], [A], [B], None, None, 1.0, None)
+        dx_ref, dA_ref, dB_ref, _ = O.sow_backward(dy, x, [A], [B], None, None, 1.0, False)
+        c = stack.calls[li]
+        assert rel_err(c.y[rows.to(DEV)].float().cpu(), y_ref) < 2e-2, ("y", li)
+        assert rel_err(c.dx[rows.to(DEV)].float().cpu(), dx_ref[rows]) < 2e-2, ("dx", li)
+        assert rel_err(stack.A[li].grad.float().cpu(), dA_ref[0]) < 2e-2, ("dA", li)
+        assert rel_err(stack.B[li].grad.float().cpu(), dB_ref[0]) < 2e-2, ("dB", li)
