@@ -232,6 +232,47 @@ int sow_ttadam_dense(float* param, const float* grad, float* exp_avg, float* exp
 int sow_tt_kron_core(const float* A, const float* B, float* out, int ra0, int rb0, int ij, int ra1, int rb1,
                      void* stream);
 
+/* Tensor-train optimizer state on device, batched over trains.  A train is described by its fp32 cores
+ * (core k: [ranks[k], in_dims[k], out_dims[k], ranks[k+1]], contiguous, ranks[0] = ranks[order] = 1) and the shape
+ * [rows, cols] of the matrix it represents (rows <= prod(in_dims), cols <= prod(out_dims): TensorTrain.from_matrix pads,
+ * to_matrix un-pads -- tt.py:48-67, 242-247, utils.py:78-87).  ranks <= 32, order <= SOW_TT_MAX_ORDER, ranks[k+1] <=
+ * ranks[k] * in_dims[k] * out_dims[k]; anything else returns SOW_ERR_UNSUPPORTED (the caller keeps the per-train path).
+ *   sow_tt_reconstruct_batch  out_i[rows, cols] = TensorTrain.to_matrix (tt.py:213-247), one launch per 16 trains;
+ *   sow_tt_decompose_batch    cores_i <- TensorTrain.from_matrix(mat_i, ranks, padding=True) (tt.py:48-67 + decompose
+ *                             :111-140: sequential truncated complete-mode QR, LAPACK sign convention): per bond ONE
+ *                             Householder-panel launch for all trains; workspace per train:
+ *                             sow_tt_decompose_workspace_bytes;
+ *   sow_ttadam_batch          TTAdam.step (ttadam.py:68-115) for n parameters: reconstruct m and v, clamp v < 0, Adam
+ *                             update of the parameter (+ the decoupled weight-decay line :110-111), re-decompose both
+ *                             moments into the cores given (in place over the old ones); has_state = 0 on the first step
+ *                             (m = v = 0).  step_size already carries the bias correction of :95-100.  Workspace per
+ *                             item: sow_ttadam_workspace_bytes(&item.m). */
+#define SOW_TT_MAX_ORDER 6
+typedef struct sow_tt_desc {
+  void* cores[SOW_TT_MAX_ORDER];
+  int32_t order;
+  int32_t ranks[SOW_TT_MAX_ORDER + 1];
+  int32_t in_dims[SOW_TT_MAX_ORDER];
+  int32_t out_dims[SOW_TT_MAX_ORDER];
+  int32_t rows, cols;
+} sow_tt_desc;
+typedef struct sow_ttadam_item {
+  sow_tt_desc m, v;        /* exp_avg / exp_avg_sq trains (read when has_state, always written) */
+  float* param;            /* [rows, cols] fp32, row pitch ld_param */
+  const float* grad;
+  int64_t ld_param, ld_grad;
+  float step_size, lr_times_wd;
+  int32_t has_state;
+  void* workspace;
+  size_t workspace_bytes;
+} sow_ttadam_item;
+size_t sow_tt_decompose_workspace_bytes(const sow_tt_desc* tt);
+size_t sow_ttadam_workspace_bytes(const sow_tt_desc* tt);
+int sow_tt_reconstruct_batch(const sow_tt_desc* tts, void* const* out, const int64_t* ld_out, int n, void* stream);
+int sow_tt_decompose_batch(const sow_tt_desc* tts, const void* const* mats, const int64_t* ld, int n, void* const* workspaces,
+                           const size_t* workspace_bytes, void* stream);
+int sow_ttadam_batch(const sow_ttadam_item* items, int n, float beta1, float beta2, float eps, void* stream);
+
 /* out[0] = max |x[i]| over n fp32 elements (TensorTrain.sqrt / sqrtinv scaling, tt.py:288, 322). */
 int sow_absmax(const float* x, int64_t n, float* out, void* stream);
 

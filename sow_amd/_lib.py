@@ -39,6 +39,23 @@ class AccumulateArgs(ctypes.Structure):
                 ("scale", c_float), ("acc_beta", c_float), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
+TT_MAX_ORDER = 6
+
+
+class TtDesc(ctypes.Structure):
+    """sow_tt_desc of include/sow_amd.h."""
+    _fields_ = [("cores", c_void_p * TT_MAX_ORDER), ("order", ctypes.c_int32), ("ranks", ctypes.c_int32 * (TT_MAX_ORDER + 1)),
+                ("in_dims", ctypes.c_int32 * TT_MAX_ORDER), ("out_dims", ctypes.c_int32 * TT_MAX_ORDER),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+
+
+class TtAdamItem(ctypes.Structure):
+    """sow_ttadam_item of include/sow_amd.h."""
+    _fields_ = [("m", TtDesc), ("v", TtDesc), ("param", c_void_p), ("grad", c_void_p), ("ld_param", c_int64),
+                ("ld_grad", c_int64), ("step_size", c_float), ("lr_times_wd", c_float), ("has_state", ctypes.c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 # name -> (restype, argtypes); mirrors include/sow_amd.h one to one
 SIGNATURES = {
     "sow_version": (c_int, []),
@@ -74,6 +91,12 @@ SIGNATURES = {
     "sow_ttadam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                  c_float, c_int, c_void_p]),
     "sow_tt_kron_core": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sow_tt_decompose_workspace_bytes": (c_size_t, [POINTER(TtDesc)]),
+    "sow_ttadam_workspace_bytes": (c_size_t, [POINTER(TtDesc)]),
+    "sow_tt_reconstruct_batch": (c_int, [POINTER(TtDesc), POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p]),
+    "sow_tt_decompose_batch": (c_int, [POINTER(TtDesc), POINTER(c_void_p), POINTER(c_int64), c_int, POINTER(c_void_p),
+                                       POINTER(c_size_t), c_void_p]),
+    "sow_ttadam_batch": (c_int, [POINTER(TtAdamItem), c_int, c_float, c_float, c_float, c_void_p]),
     "sow_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sow_small_inverse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sow_axpby": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),

@@ -12,6 +12,7 @@
 // caller's parameter storage -- and any flat bucket that views it -- stays where it is.
 #include "kernels.hpp"
 #include "qr_panel.hpp"
+#include <vector>
 
 namespace sow {
 
@@ -84,12 +85,8 @@ template <typename Tin> __global__ void qr_copy_in_batch_kernel(const AccBatch b
 }
 
 // the panel kernel is latency-bound (0.5 - 1.3 ms per matrix on one CU) and needs four words per layer: its own compact
-// descriptor block lets ONE launch cover up to 112 layers (the slowest matrix sets the time, not the sum over launches)
-struct QrItem {
-  float* Pt;
-  float* Qt;
-  int m, kc, r_new, pad;
-};
+// descriptor block (kernels.hpp: QrItem) lets ONE launch cover up to 112 matrices (the slowest matrix sets the time, not
+// the sum over launches)
 constexpr int QR_MAXB = 112;   // 112 x 32 bytes of kernel arguments
 struct QrBatch {
   QrItem it[QR_MAXB];
@@ -99,6 +96,29 @@ __global__ __launch_bounds__(1024) void qr_panel_batch_kernel(const QrBatch b) {
   extern __shared__ __attribute__((aligned(16))) float qsm_b[];
   const QrItem& it = b.it[blockIdx.x];
   qr_panel_body(it.Pt, it.Qt, it.m, it.kc, it.r_new, qsm_b);
+}
+
+// Householder panel + org2r of n independent matrices, one workgroup each, QR_MAXB per launch (also used by tt_batch.hip)
+int launch_qr_panel_batch(const QrItem* items, int n, hipStream_t stream) {
+  for (int i = 0; i < n; ++i) {
+    if (items[i].m <= 0 || items[i].kc <= 0 || items[i].kc > items[i].m || items[i].r_new <= 0 || items[i].r_new > items[i].m)
+      return SOW_ERR_SHAPE;
+    if (qr_panel_lds_bytes(items[i].m, items[i].kc) > 150 * 1024) return SOW_ERR_UNSUPPORTED;
+  }
+  for (int base = 0; base < n; base += QR_MAXB) {
+    QrBatch q{};
+    q.n = n - base < QR_MAXB ? n - base : QR_MAXB;
+    size_t max_lds = 0;
+    for (int i = 0; i < q.n; ++i) {
+      q.it[i] = items[base + i];
+      const size_t l = qr_panel_lds_bytes(q.it[i].m, q.it[i].kc);
+      if (l > max_lds) max_lds = l;
+    }
+    SOW_SET_MAX_LDS_ONCE(150 * 1024, qr_panel_batch_kernel);
+    hipLaunchKernelGGL(qr_panel_batch_kernel, dim3(q.n), dim3(1024), max_lds, stream, q);
+    SOW_CHECK_LAUNCH();
+  }
+  return SOW_OK;
 }
 
 template <typename Tout> __global__ void qr_copy_out_batch_kernel(const AccBatch b) {
@@ -154,27 +174,11 @@ int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t 
     SOW_CHECK_LAUNCH();
   }
   {
-    QrBatch q{};
-    size_t max_lds = 0;
-    auto flush = [&]() {
-      if (q.n == 0) return;
-      SOW_SET_MAX_LDS_ONCE(150 * 1024, qr_panel_batch_kernel);
-      hipLaunchKernelGGL(qr_panel_batch_kernel, dim3(q.n), dim3(1024), max_lds, stream, q);
-      q.n = 0, max_lds = 0;
-    };
-    for (int i = 0; i < n; ++i) {
-      const AccItem& it = items[i];
-      if (!it.draw) continue;
-      q.it[q.n++] = QrItem{it.Pt, it.Qt, it.d_in, it.kc, it.r_new, 0};
-      const size_t l = qr_panel_lds_bytes(it.d_in, it.kc);
-      if (l > max_lds) max_lds = l;
-      if (q.n == QR_MAXB) {
-        flush();
-        SOW_CHECK_LAUNCH();
-      }
-    }
-    flush();
-    SOW_CHECK_LAUNCH();
+    std::vector<QrItem> qs;
+    for (int i = 0; i < n; ++i)
+      if (items[i].draw) qs.push_back(QrItem{items[i].Pt, items[i].Qt, items[i].d_in, items[i].kc, items[i].r_new, 0});
+    const int rc = launch_qr_panel_batch(qs.data(), (int)qs.size(), stream);
+    if (rc) return rc;
   }
   for (int base = 0; base < n; base += ACC_MAXB) {
     AccBatch b;

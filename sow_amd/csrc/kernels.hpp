@@ -177,6 +177,14 @@ int launch_qr_panel(const void* W, int64_t ldw, int in_dtype, int m, int kc, int
                     hipStream_t stream);
 int launch_qr_copy_out(const float* Qt, const float* Pt, void* Q, int64_t ldq, void* R, int64_t ldr, int out_dtype, int m,
                        int kc, int r, int k_rows, hipStream_t stream);
+// accumulate.hip: batched Householder panels (one 1024-thread workgroup per matrix; Pt [kc][m] column-major panel in,
+// factored in place; Qt [r_new][m] = Q[:, :r_new] out)
+struct QrItem {
+  float* Pt;
+  float* Qt;
+  int m, kc, r_new, pad;
+};
+int launch_qr_panel_batch(const QrItem* items, int n, hipStream_t stream);
 // accumulate.hip: the periodic step of many layers, one launch per phase
 struct AccItem {
   void* acc;            // [d_in, d_out] dense accumulator, acc = beta * acc + scale * A . B

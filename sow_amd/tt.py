@@ -354,3 +354,85 @@ class TensorTrain:
             cores.append(nn.Parameter(core))
         self.cores = cores
         return self
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched entry points: many trains per launch through sow_tt_reconstruct_batch / sow_tt_decompose_batch
+# ---------------------------------------------------------------------------------------------------------------------
+def _tt_desc(cores, ranks, input_shape, output_shape, rows, cols):
+    """sow_tt_desc (include/sow_amd.h) of a train whose cores are fp32 contiguous device tensors; None when the batched
+    kernels do not cover it (rank > 32, order > 6, a truncation rank larger than its unfolding, CPU cores)."""
+    from . import _lib
+    order = len(cores)
+    if order < 1 or order > _lib.TT_MAX_ORDER or max(ranks) > 32 or ranks[0] != 1 or ranks[-1] != 1:
+        return None
+    for k, c in enumerate(cores):
+        if not (c.is_cuda and c.dtype == torch.float32 and c.is_contiguous()):
+            return None
+        if k + 1 < order and ranks[k + 1] > ranks[k] * input_shape[k] * output_shape[k]:
+            return None
+    d = _lib.TtDesc()
+    d.order = order
+    for k in range(order):
+        d.cores[k] = cores[k].data_ptr()
+        d.in_dims[k], d.out_dims[k] = int(input_shape[k]), int(output_shape[k])
+    for k in range(order + 1):
+        d.ranks[k] = int(ranks[k])
+    d.rows, d.cols = int(rows), int(cols)
+    return d
+
+
+def _empty_train(ranks, shape, device):
+    """Cores (uninitialised) of the train TensorTrain.from_matrix(matrix of `shape`, ranks, padding=True) would return."""
+    order = len(ranks) - 1
+    mm, nn_ = ceil(shape[0] ** (1 / order)), ceil(shape[1] ** (1 / order))     # tt.py:53-54, double pow + ceil
+    tt = TensorTrain(list(ranks), (mm,) * order, (nn_,) * order)
+    tt.cores = [torch.empty(s, dtype=torch.float32, device=device) for s in tt._core_shapes()]
+    tt.device = device
+    return tt
+
+
+def to_matrix_batch(trains, shapes):
+    """[tt.to_matrix(shape) for tt, shape in zip(trains, shapes)] in one launch per 16 trains (reference tt.py:213-247)."""
+    import ctypes
+
+    from . import _lib
+    descs = [_tt_desc(t.cores, t.ranks, t.input_shape, t.output_shape, s[0], s[1]) for t, s in zip(trains, shapes)]
+    if not trains or any(d is None for d in descs):
+        return [t.to_matrix(s) for t, s in zip(trains, shapes)]
+    dev = trains[0].cores[0].device
+    outs = [torch.empty(tuple(s), dtype=torch.float32, device=dev) for s in shapes]
+    n = len(trains)
+    arr = (_lib.TtDesc * n)(*descs)
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    lds = (ctypes.c_int64 * n)(*[o.stride(0) for o in outs])
+    ops._launch(dev, "sow_tt_reconstruct_batch", _lib.load().sow_tt_reconstruct_batch, arr, ptrs, lds, n)
+    return outs
+
+
+def from_matrix_batch(matrices, ranks):
+    """[TensorTrain.from_matrix(m, ranks, padding=True) for m in matrices] with ONE Householder-panel launch per bond for
+    all of them (reference tt.py:48-67, 111-140)."""
+    import ctypes
+
+    from . import _lib
+    if not matrices:
+        return []
+    lib = _lib.load()
+    dev = matrices[0].device
+    mats = [m if (m.dtype == torch.float32 and m.stride(1) == 1) else m.float().contiguous() for m in matrices]
+    trains = [_empty_train(ranks, m.shape, dev) if m.is_cuda else None for m in mats]
+    descs = [None if t is None else _tt_desc(t.cores, t.ranks, t.input_shape, t.output_shape, m.shape[0], m.shape[1])
+             for t, m in zip(trains, mats)]
+    if any(d is None for d in descs):
+        return [TensorTrain.from_matrix(m, ranks=ranks, padding=True) for m in matrices]
+    n = len(mats)
+    arr = (_lib.TtDesc * n)(*descs)
+    sizes = [int(lib.sow_tt_decompose_workspace_bytes(ctypes.byref(d))) for d in descs]
+    ws = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
+    src = (ctypes.c_void_p * n)(*[m.data_ptr() for m in mats])
+    lds = (ctypes.c_int64 * n)(*[m.stride(0) for m in mats])
+    wsp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    wsb = (ctypes.c_size_t * n)(*sizes)
+    ops._launch(dev, "sow_tt_decompose_batch", lib.sow_tt_decompose_batch, arr, src, lds, n, wsp, wsb)
+    return trains
