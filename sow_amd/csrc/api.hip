@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
                                                    "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
-                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4"};
+                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -272,6 +272,11 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
     if (r_live <= 64 && h_save) {
       // one product with the low-rank term as a K-extension:  y = [x, h] . [W_acc; B] + bias,  h = scale * x . A
       // -- in one launch (h projected inside the GEMM) when d_out spans at most two column tiles
+      // gemm4h: projection pass + anti-phase main loop in one launch, A read in place
+      if (gemm4h_supported(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in, r_live,
+                           dtype))
+        return launch_gemm4h(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in,
+                             r_live, scale, stream);
       if (gemm2h_supported(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in,
                            r_live, dtype))
         return launch_gemm2h(x, d_in, acc_down, d_out, false, A, r_live, B, d_out, y, d_out, bias, h_save, T, d_out, d_in,
@@ -379,7 +384,14 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       pd.F1b = B, pd.ldf1b = d_out, pd.F2b = A, pd.ldf2b = r_live, pd.rb = r_live;
       pd.scale = scale, pd.beta = 0.f;
       void* apad = ws + w.off_apad;
-      if (gemm2h_supported(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out,
+      if (gemm4h_supported(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out, r_live,
+                           dtype)) {
+        // one launch: dh projected by the kernel's own pass over dY, A^T read from A's own 2r-byte rows
+        rc = launch_gemm4h(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out, r_live,
+                           scale, stream);
+        if (rc) return rc;
+        data_done = true;
+      } else if (gemm2h_supported(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out,
                            r_live, dtype)) {
         // one launch: dh projected inside the GEMM, A^T read from A's own 2r-byte rows
         rc = launch_gemm2h(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out,
@@ -581,6 +593,15 @@ int sow_forward_group(const sow_layer_args* layers, int n, int dtype, void* stre
       }
       continue;
     }
+    // dense accumulator: gemm4h (one launch per layer) where it applies
+    if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 && L.h_save &&
+        gemm4h_supported(L.x, L.d_in, L.acc_down, L.d_out, false, L.A, L.r_live, L.B, L.d_out, L.y, L.d_out, L.bias, L.h_save, L.T,
+                         L.d_out, L.d_in, L.r_live, dtype)) {
+      if ((rc = launch_gemm4h(L.x, L.d_in, L.acc_down, L.d_out, false, L.A, L.r_live, L.B, L.d_out, L.y, L.d_out, L.bias, L.h_save,
+                              L.T, L.d_out, L.d_in, L.r_live, L.scale, stream)))
+        return rc;
+      continue;
+    }
     // dense accumulator, one launch per layer (gemm2h): the layers of a group share the grid
     if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 && L.h_save && !sw_on(SW_NO_GROUPED) &&
         gemm2h_supported(L.x, L.d_in, L.acc_down, L.d_out, false, L.A, L.r_live, L.B, L.d_out, L.y, L.d_out, L.bias, L.h_save, L.T,
@@ -640,6 +661,12 @@ int sow_backward_group(const sow_layer_args* layers, int n, int dtype, int phase
           if ((rc = launch_chain2_group(batch, nb, true, stream))) return rc;
           nb = 0;
         }
+      } else if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 &&
+                 gemm4h_supported(L.dy, L.d_out, L.acc_down, L.d_out, true, L.B, L.d_out, L.A, L.r_live, L.dx, L.d_in, nullptr, dh,
+                                  L.T, L.d_in, L.d_out, L.r_live, dtype)) {
+        if ((rc = launch_gemm4h(L.dy, L.d_out, L.acc_down, L.d_out, true, L.B, L.d_out, L.A, L.r_live, L.dx, L.d_in, nullptr, dh,
+                                L.T, L.d_in, L.d_out, L.r_live, L.scale, stream)))
+          return rc;
       } else if (L.acc_kind == SOW_ACC_DENSE && L.r_live <= 64 && !sw_on(SW_NO_GROUPED) &&
                  gemm2h_supported(L.dy, L.d_out, L.acc_down, L.d_out, true, L.B, L.d_out, L.A, L.r_live, L.dx, L.d_in, nullptr, dh,
                                   L.T, L.d_in, L.d_out, L.r_live, dtype)) {

@@ -139,6 +139,7 @@ enum Switch : int {
   SW_TN_NO_NT_LOAD,       // row-owner weight-gradient kernel streams x / dY with plain (cached) loads
   SW_NO_TN_ROWS,          // grouped weight-gradient launches never use the row-owner kernel (group-planned slabs)
   SW_GEMM4,               // 1 / 0: force / forbid gemm4 (anti-phase wave groups, 64-wide K-tiles)
+  SW_NO_GEMM4H,           // dense-accumulator layer with the projection inside the kernel: gemm2h instead of gemm4h
   SW_COUNT
 };
 int sw(int which);

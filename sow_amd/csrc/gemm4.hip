@@ -42,6 +42,9 @@ constexpr int G4_LDS = 2 * G4_BUF;         // 128 KiB
 constexpr int G4_OFF_A0 = 0, G4_OFF_A1 = G4_HALF, G4_OFF_B0 = 2 * G4_HALF, G4_OFF_B1 = 3 * G4_HALF;
 constexpr int G4_SCR_LD = 68;              // floats per scratch row (64 + 4: 16-byte aligned rows, staggered banks)
 constexpr int G4_SCR = 16 * G4_SCR_LD * 4; // bytes of one wave's epilogue scratch
+constexpr int G4_HIMG = G4_LDS;            // gemm4h: the projected [256][64] tile, two half images of 16 KiB behind the ring
+constexpr int G4_LDS_H = G4_LDS + 2 * G4_HALF;   // 160 KiB
+constexpr int G4_PA_BUF = 2 * G4_HALF + 8192;    // gemm4h projection pass: A0 | A1 | F (8 KiB) per K-tile, three buffers in the ring
 
 struct Gemm4Params {
   const bf16_t* A;
@@ -52,8 +55,17 @@ struct Gemm4Params {
   const bf16_t* bias;
   int64_t M, lda, ldb, lda2, ldb2, ldc;
   int N, K, k2;
+  int k2e;            // NT: valid k columns of B2's rows (64: zero-padded rows; r: raw [N][r] rows, gemm4h)
   float alpha, beta;
   int nt_store;
+  // HF = true (gemm4h): the rank-r projection H = hscale * A . op(F) is computed by the kernel itself and is the extension's
+  // A operand (A2 is not read): F is [r, K] (NT, ld ldf) or a zero-padded [K, 64] (NN, ld ldf); Hout [M, 64] receives the
+  // saved copy (column 63 <- 1.0 when r < 64) from the first column tile
+  const bf16_t* F;
+  int64_t ldf;
+  bf16_t* Hout;
+  int r;
+  float hscale;
 };
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
@@ -103,7 +115,7 @@ template <int KIND> __device__ __forceinline__ constexpr int g4_slot_off() {
   return KIND == G4_A0 ? G4_OFF_A0 : KIND == G4_A1 ? G4_OFF_A1 : KIND == G4_B0 ? G4_OFF_B0 : G4_OFF_B1;
 }
 
-template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(const Gemm4Params p) {
+template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(const Gemm4Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -116,7 +128,8 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
   const int K = p.K, N = p.N;
   const int64_t M = p.M;
   const int nfull = K / G4_BK;
-  const int NTL = nfull + ((K % G4_BK) ? 1 : 0) + (p.A2 ? 1 : 0);   // K-tiles
+  const bool has_ext = HF || p.A2 != nullptr;
+  const int NTL = nfull + ((K % G4_BK) ? 1 : 0) + (has_ext ? 1 : 0);   // K-tiles
   const int H = 4 * NTL;                                            // half-tiles
   const char* zp = zero_page_for(lane);
 
@@ -180,7 +193,7 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
       return;
     }
     // checked path: the K tail of the main operands, or the extension tile
-    const bool ext = p.A2 != nullptr && tile == NTL - 1;
+    const bool ext = has_ext && tile == NTL - 1;
     const int k0 = ext ? 0 : nfull * G4_BK;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
@@ -190,13 +203,19 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
         const int64_t ld = ext ? p.lda2 : p.lda;
         const int klim = ext ? 64 : K;
         const int kk = k0 + 8 * c_q[ii];
-        src = kk < klim ? (const void*)(base + a_row(HH, c_lr[ii]) * ld + kk) : (const void*)zp;
+        // gemm4h: the extension's A operand is the projected tile in LDS; the DMA slot is filled with zeros only to keep
+        // the counted waits uniform
+        src = (kk < klim && !(HF && ext)) ? (const void*)(base + a_row(HH, c_lr[ii]) * ld + kk) : (const void*)zp;
       } else if constexpr (NT) {
         const bf16_t* base = ext ? p.B2 : p.B;
         const int64_t ld = ext ? p.ldb2 : p.ldb;
-        const int klim = ext ? 64 : K;
+        const int klim = ext ? p.k2e : K;
         const int kk = k0 + 8 * c_q[ii];
-        src = kk < klim ? (const void*)(base + (int64_t)b_col_nt(HH, c_lr[ii]) * ld + kk) : (const void*)zp;
+        const int64_t eoff = (int64_t)b_col_nt(HH, c_lr[ii]) * ld + kk;
+        // gemm4h: B2 = A as stored ([N][r], 2r-byte rows): pieces straddling r carry the next row's head (they meet the
+        // exact zeros of H's ranks >= r); the piece that would cross the end of the buffer reads zeros, patched before use
+        const bool ok = kk < klim && !(HF && ext && eoff + 8 > (int64_t)N * ld);
+        src = ok ? (const void*)(base + eoff) : (const void*)zp;
       } else {
         const bf16_t* base = ext ? p.B2 : p.B;
         const int64_t ld = ext ? p.ldb2 : p.ldb;
@@ -211,6 +230,138 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
   using KB0 = std::integral_constant<int, G4_B0>;
   using KB1 = std::integral_constant<int, G4_B1>;
   using KA1 = std::integral_constant<int, G4_A1>;
+
+  // ------------------------------------------------------------------ gemm4h: projection pass H^T = F' . A^T over all of K
+  // A lighter pipeline of its own (HBM-bound: the row panel streams in once, the main loop below re-reads it from L2 /
+  // the Infinity Cache): three 40-KiB buffers in the ring, two K-tiles in flight, every wave the same schedule.  Wave
+  // (wr, wc) owns rows 128 wr .. + 127 x ranks 16 wc .. + 15 (32 accumulator registers, dead before the main loop starts).
+  if constexpr (HF) {
+    const int NTA = (K + G4_BK - 1) / G4_BK;
+    const int f_row = 8 * w + (lane >> 3);     // NT: rank row of F; NN: k row of the padded [K][64] factor
+    const int f_pc = lane & 7;
+    const int f_q = NT ? (f_pc ^ ((f_row >> 1) & 7)) : (f_pc ^ ((((lane >> 4) & 1) | ((w & 1) << 1)) << 1));
+    auto issue_a = [&](int tl) {
+      char* buf = smem + (tl % 3) * G4_PA_BUF;
+      const int k0 = tl * G4_BK;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const void* src = (k0 + 8 * c_q[ii] < K) ? (const void*)pA[hh][ii] : (const void*)zp;
+          dma16(src, buf + hh * G4_HALF + (2 * w + ii) * 1024);
+          pA[hh][ii] += G4_BK;
+        }
+      const void* fs;
+      if constexpr (NT) {
+        const int kk = k0 + 8 * f_q;
+        fs = (f_row < p.r && kk < K) ? (const void*)(p.F + (int64_t)f_row * p.ldf + kk) : (const void*)zp;
+      } else {
+        // F = A as stored ([K][r], 2r-byte rows, r even): a 16-byte piece may carry the head of the next row -- those are
+        // ranks >= r, masked when H is written -- and the ONE piece that would cross the end of the buffer (last row,
+        // straddling piece) reads zeros and is patched below
+        const int gk = k0 + f_row;
+        const int64_t eoff = (int64_t)gk * p.ldf + 8 * f_q;
+        const bool ok = gk < K && 8 * f_q < p.r && eoff + 8 <= (int64_t)K * p.ldf;
+        fs = ok ? (const void*)(p.F + eoff) : (const void*)zp;
+      }
+      dma16(fs, buf + 2 * G4_HALF + w * 1024);
+    };
+    auto patch_f = [&](int tl) {   // after this wave's pieces of tile tl have landed, before the barrier that publishes them
+      if constexpr (!NT) {
+        const int gk = tl * G4_BK + f_row;
+        const int64_t eoff = (int64_t)gk * p.ldf + 8 * f_q;
+        if (gk < K && 8 * f_q < p.r && eoff + 8 > (int64_t)K * p.ldf) {
+          u32x4 v;
+          bf16_t* e = (bf16_t*)&v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = (8 * f_q + j < p.r) ? p.F[eoff + j] : (bf16_t)0.f;
+          *(u32x4*)(smem + (tl % 3) * G4_PA_BUF + 2 * G4_HALF + w * 1024 + lane * 16) = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    };
+    const uint32_t lbase = lds_addr(smem);
+    const int fsw_a = (r16 >> 1) & 7;
+    const int cha = (fsw_a & 4) | (g ^ (fsw_a & 3));
+    const uint32_t ar0 = lbase + (uint32_t)((wr * 64 + r16) * 128 + cha * 16);
+    const uint32_t ar1 = lbase + (uint32_t)((wr * 64 + r16) * 128 + (cha ^ 4) * 16);
+    uint32_t fr0, fr1;
+    if constexpr (NT) {
+      fr0 = lbase + (uint32_t)(2 * G4_HALF + (wc * 16 + r16) * 128 + cha * 16);
+      fr1 = lbase + (uint32_t)(2 * G4_HALF + (wc * 16 + r16) * 128 + (cha ^ 4) * 16);
+    } else {
+      const int qq = r16 >> 2, pp = r16 & 3;
+      const int ff_sw = (((qq >> 1) & 1) | ((g & 1) << 1)) << 1;
+      const int chunk = wc * 2 + (pp >> 1);
+      fr0 = lbase + (uint32_t)(2 * G4_HALF + (8 * g + qq) * 128 + ((chunk ^ ff_sw) * 16) + 8 * (pp & 1));
+      fr1 = fr0;
+    }
+    f32x4 hacc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue_a(0);
+    if (NTA > 1) issue_a(1);
+#pragma unroll 1
+    for (int tl = 0; tl < NTA; ++tl) {
+      wait_groups<5>(NTA - 1 - tl < 1 ? NTA - 1 - tl : 1);
+      if (tl == NTA - 1) patch_f(tl);   // the only tile that holds the last row of F
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl + 2 < NTA) issue_a(tl + 2);
+      const uint32_t bo = (uint32_t)((tl % 3) * G4_PA_BUF);
+      u32x4 xa[4][2], ffr[2];
+      u32x2 fl[2], fh[2];
+      g4_read_a<0>(xa, ar0 + bo, ar1 + bo);
+      if constexpr (NT) {
+        g4_rd128<0>(ffr[0], fr0 + bo);
+        g4_rd128<0>(ffr[1], fr1 + bo);
+      } else {
+        g4_rdtr<0>(fl[0], fr0 + bo);
+        g4_rdtr<512>(fh[0], fr0 + bo);
+        g4_rdtr<4096>(fl[1], fr0 + bo);
+        g4_rdtr<4096 + 512>(fh[1], fr0 + bo);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!NT) ffr[0] = join2(fl[0], fh[0]), ffr[1] = join2(fl[1], fh[1]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) hacc[0][mt] = mfma16(ffr[ks], xa[mt][ks], hacc[0][mt]);
+      __builtin_amdgcn_sched_barrier(0);
+      g4_read_a<1>(xa, ar0 + bo, ar1 + bo);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) hacc[1][mt] = mfma16(ffr[ks], xa[mt][ks], hacc[1][mt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // H^T tile (rows = rank 4 g + j of rank tile wc, column = token r16) -> bf16 -> the k-contiguous image the extension reads
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int lr = wr * 64 + mt * 16 + r16;
+        const int q = wc * 2 + (g >> 1);
+        char* dst = smem + G4_HIMG + mh * G4_HALF + lr * 128 + ((q ^ ((lr >> 1) & 7)) * 16) + (g & 1) * 8;
+        f32x4 v = hacc[mh][mt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (wc * 16 + 4 * g + j < p.r) ? v[j] * p.hscale : 0.f;   // ranks >= r: exact zeros
+        *(u32x2*)dst = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every read of the projection buffers is done: the ring belongs to the main loop
+    __builtin_amdgcn_sched_barrier(0);
+    // the main loop starts over at k = 0
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) pA[hh][ii] = p.A + a_row(hh, c_lr[ii]) * p.lda + 8 * c_q[ii];
+  }
 
   // ------------------------------------------------------------------ fragment addresses (per lane)
   const uint32_t base = lds_addr(smem);
@@ -334,7 +485,46 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
     phase(P3{}, T0{}, tile);
   }
 #pragma unroll 1
-  for (; tile < NTL; ++tile) {
+  for (; tile < NTL - 1; ++tile) {
+    phase(P0{}, T1{}, tile);
+    phase(P1{}, T1{}, tile);
+    phase(P2{}, T1{}, tile);
+    phase(P3{}, T1{}, tile);
+  }
+  // the last K-tile, outside the loop (gemm4h: the extension tile, with its operand switch and the end-of-buffer patch)
+  if (tile < NTL) {
+    if constexpr (HF) {
+      if (tile == NTL - 1) {   // the extension tile: A fragments come from the projected tile
+        a_off[0] = base + (uint32_t)(G4_HIMG + (wr * 64 + r16) * 128 + ch0 * 16);
+        a_off[1] = base + (uint32_t)(G4_HIMG + (wr * 64 + r16) * 128 + (ch0 ^ 4) * 16);
+        if constexpr (NT) {
+          if (p.ldb2 != 64) {
+            // B2 = raw A: rewrite the pieces that crossed the end of the buffer (every DMA has been issued by now).  Two
+            // barriers: the wave rows are one barrier apart, and the other row's patch must be visible before the reads
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii) {
+                const int kk = 8 * c_q[ii];
+                const int64_t eoff = (int64_t)b_col_nt(hh, c_lr[ii]) * p.ldb2 + kk;
+                if (kk < p.k2e && eoff + 8 > (int64_t)N * p.ldb2) {
+                  u32x4 v;
+                  bf16_t* e = (bf16_t*)&v;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) e[j] = (kk + j < p.k2e) ? p.B2[eoff + j] : (bf16_t)0.f;
+                  *(u32x4*)(smem + (tile & 1) * G4_BUF + (hh ? G4_OFF_B1 : G4_OFF_B0) + (2 * w + ii) * 1024 + lane * 16) = v;
+                }
+              }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
     phase(P0{}, T1{}, tile);
     phase(P1{}, T1{}, tile);
     phase(P2{}, T1{}, tile);
@@ -388,6 +578,24 @@ template <bool NT> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel
       }
       __builtin_amdgcn_wave_barrier();
     }
+  // gemm4h: the saved copy of the projection (h_save / dh: [M, 64], column 63 <- 1.0 when free -- the dbias column of the
+  // weight-gradient kernels), written once per row panel, after the C stores
+  if constexpr (HF) {
+    if (n0 == 0 && p.Hout) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * G4_THREADS + t;
+        const int half = idx >> 10, lr = (idx >> 3) & 127, pc = idx & 7;
+        const int q = pc ^ ((lr >> 1) & 7);
+        const int64_t grow = m0 + (lr >> 6) * 128 + half * 64 + (lr & 63);
+        if (grow < M) {
+          u32x4 v = *(const u32x4*)(smem + G4_HIMG + half * G4_HALF + lr * 128 + pc * 16);
+          if (q == 7 && p.r < 64) v[3] = (v[3] & 0xffffu) | 0x3F800000u;
+          *(u32x4*)(p.Hout + grow * 64 + q * 8) = v;
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,17 +621,68 @@ int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias;
   p.M = M, p.lda = lda, p.ldb = ldb, p.lda2 = lda2, p.ldb2 = ldb2, p.ldc = ldc;
   p.N = N, p.K = K, p.k2 = k2 < 64 ? k2 : 64;
+  p.k2e = 64;
   p.alpha = alpha, p.beta = beta;
   p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
+  p.F = nullptr, p.ldf = 0, p.Hout = nullptr, p.r = 0, p.hscale = 0.f;
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
   if (nt) {
-    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<true>);
-    hipLaunchKernelGGL(gemm4_kernel<true>, dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<true, false>);
+    hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
   } else {
-    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<false>);
-    hipLaunchKernelGGL(gemm4_kernel<false>, dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<false, false>);
+    hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+  }
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+// ---- gemm4h: C = X . op(W) + H . op(G) + bias with H = hscale * X . op(F) computed in the kernel and saved -------------
+// NN (forward: y = x W_acc + h B): W [K, N], F = A zero-padded to [K, 64] (ldf = 64), G = B [r, N].
+// NT (backward: dX = dY W_acc^T + dh A^T): W [N, K], F = B [r, K], G = A zero-padded to [N, 64] (ldg = 64).
+bool gemm4h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
+                      const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,
+                      int N, int K, int r, int dtype) {
+  if (dtype != SOW_BF16 || !X || !W || !F || !G || !C || !H) return false;
+  if (sw_on(SW_NO_FUSED_H) || sw_on(SW_FORCE_GEMM_V1) || sw(SW_GEMM4) == 0 || sw_on(SW_NO_GEMM4H)) return false;
+  if (r < 2 || r > 64 || (r & 1) || N < 64 || K < 64) return false;   // r even: A's 2r-byte rows stay 4-byte aligned
+  const int tiles_n = ceil_div(N, G4_BN);
+  // every column tile repeats the projection pass (the row panel streams in once more per tile): one or two tiles
+  if (tiles_n > 2 || (int64_t)ceil_div(M, G4_BM) * tiles_n < 120) return false;
+  if (K % 8 || N % 8 || ldx % 8 || ldw % 8 || ldc % 8) return false;
+  if (!g4_al16(X) || !g4_al16(W) || !g4_al16(C) || !g4_al16(H) || (bias && !g4_al16(bias))) return false;
+  auto al4 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
+  if (nt) {   // F = B [r, K] (16-byte pieces along rows), G = A [N, r] as stored (or zero-padded to 64 columns)
+    if (ldf % 8 || !g4_al16(F) || !al4(G) || (ldg != r && ldg != 64)) return false;
+  } else {    // F = A [K, r] as stored (or [K, 64]), G = B [r, N]
+    if (ldg % 8 || !g4_al16(G) || !al4(F) || (ldf != r && ldf != 64)) return false;
+  }
+  return true;
+}
+
+int launch_gemm4h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
+                  const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
+                  int r, float hscale, hipStream_t stream) {
+  Gemm4Params p;
+  p.A = (const bf16_t*)X, p.B = (const bf16_t*)W, p.A2 = nullptr, p.B2 = (const bf16_t*)G;
+  p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias;
+  p.M = M, p.lda = ldx, p.ldb = ldw, p.lda2 = 64, p.ldb2 = ldg, p.ldc = ldc;
+  p.N = N, p.K = K, p.k2 = r < 64 ? r : 64;
+  p.k2e = nt ? (ldg == 64 ? 64 : r) : 64;
+  p.alpha = 1.f, p.beta = 0.f;
+  p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
+  p.F = (const bf16_t*)F, p.ldf = ldf, p.Hout = (bf16_t*)H, p.r = r, p.hscale = hscale;
+  const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
+  if (tiles <= 0) return SOW_OK;
+  if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
+  if (nt) {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS_H, gemm4_kernel<true, true>);
+    hipLaunchKernelGGL((gemm4_kernel<true, true>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS_H, stream, p);
+  } else {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS_H, gemm4_kernel<false, true>);
+    hipLaunchKernelGGL((gemm4_kernel<false, true>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS_H, stream, p);
   }
   SOW_CHECK_LAUNCH();
   return SOW_OK;

@@ -149,6 +149,14 @@ bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
 int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                  float alpha, float beta, hipStream_t stream);
+// gemm4.hip, gemm4h form: the projection H = hscale * X . op(F) computed by the kernel (a streaming pass over the row panel
+// ahead of the main loop) and used as the extension's A operand; F / G zero-padded to 64 columns where they are k-major
+bool gemm4h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
+                      const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,
+                      int N, int K, int r, int dtype);
+int launch_gemm4h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
+                  const void* G, int64_t ldg, void* C, int64_t ldc, const void* bias, void* H, int64_t M, int N, int K,
+                  int r, float hscale, hipStream_t stream);
 // gemm2h.hip (the same product with the projection h = hscale * X . op(F) computed in the kernel: one launch per pass)
 bool gemm2h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,
                       const void* G, int64_t ldg, const void* C, int64_t ldc, const void* bias, const void* H, int64_t M,

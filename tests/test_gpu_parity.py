@@ -177,10 +177,12 @@ FUSED_H = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["gemm4h", "gemm2h"])
 @pytest.mark.parametrize("idx", range(len(FUSED_H)))
-def test_dense_layer_with_in_kernel_projection(idx):
-    """gemm2h (projection h = s x A computed inside the dense GEMM, one launch per pass) against the oracle and against
-    the two-launch path (H-only chain + K-extended GEMM).  The last row of A is spiked so that a missing fix-up of its
+def test_dense_layer_with_in_kernel_projection(idx, kernel):
+    """gemm4h / gemm2h (projection h = s x A computed inside the dense GEMM, one launch per pass: gemm4h by a streaming pass
+    of its own ahead of the anti-phase main loop, gemm2h -- NO_GEMM4H -- alongside its main loop) against the oracle and
+    against the two-launch path (H-only chain + K-extended GEMM).  The last row of A is spiked so that a missing fix-up of its
     straddling 16-byte piece (the only piece whose tail crosses the end of the buffer) cannot hide in the tolerance."""
     from sow_amd import ops
     T, d_in, d_out, r, bias = FUSED_H[idx]
@@ -194,9 +196,10 @@ def test_dense_layer_with_in_kernel_projection(idx):
     y_ref = O.sow_forward(f(xq), [f(Aq)], [f(Bq)], f(adq), None, scale, f(bq))
     dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(f(dyq), f(xq), [f(Aq)], [f(Bq)], f(adq), None, scale, bias)
     g = lambda t: None if t is None else t.to(DEV)
-    y, h = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
-    dx, dA, dB, db = ops.sow_backward(g(dyq), g(xq), h, g(Aq), g(Bq), g(adq), None, scale, bias)
     from sow_amd import _lib
+    with _lib.switch(NO_GEMM4H=1 if kernel == "gemm2h" else 0):
+        y, h = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
+        dx, dA, dB, db = ops.sow_backward(g(dyq), g(xq), h, g(Aq), g(Bq), g(adq), None, scale, bias)
     with _lib.switch(NO_FUSED_H=1):
         y0, h0 = ops.sow_forward(g(xq), g(Aq), g(Bq), g(adq), None, g(bq), scale)
         dx0, dA0, dB0, db0 = ops.sow_backward(g(dyq), g(xq), h0, g(Aq), g(Bq), g(adq), None, scale, bias)
