@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
                                                    "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
-                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H"};
+                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H",      "NO_CHAIN3F"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -163,10 +163,11 @@ size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_l
 
 // workspace carve (identical in the query and in the calls)
 struct WsPlan {
-  size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, total;
+  size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, off_planes, planes_bytes, total;
   int ns, slab_len;
   int ns_cap;   // slabs the partial regions can hold (group-planned slab counts may exceed the single-layer choice)
 };
+constexpr int64_t C3F_MIN_T = 8192;   // chain3f_supported's threshold
 static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
   WsPlan w{};
   const size_t es = esize(dtype);
@@ -192,6 +193,14 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
     w.off_p1 = off;
     off += al256(tn_partial_bytes(w.ns_cap, d_out));
   }
+  // fp32 streaming chain (chain3f.hip): the factors of a launch pre-split into bf16 planes, 24 KiB per 64-wide chunk of
+  // d_in and of d_out (either direction; a low-rank accumulator's chain reuses the region: same stream, launch after launch)
+  w.off_planes = off;
+  w.planes_bytes = 0;
+  if (dtype == SOW_F32 && T >= C3F_MIN_T && (r_live <= 64 || (acc_kind == SOW_ACC_LOWRANK && r_acc <= 64))) {
+    w.planes_bytes = chain3f_plane_bytes(d_in, d_out);
+    off += al256(w.planes_bytes);
+  }
   w.total = off;
   return w;
 }
@@ -199,6 +208,11 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
 static char* ws_base(void* workspace) {
   uintptr_t a = reinterpret_cast<uintptr_t>(workspace);
   return reinterpret_cast<char*>((a + 255) & ~(uintptr_t)255);
+}
+// hands the factor-plane scratch of the workspace to a chain launch (fp32, long T: chain3f.hip); without it the launch
+// takes chain2f
+static void set_planes(ChainParams& p, char* ws, const WsPlan& w, size_t workspace_bytes) {
+  if (ws && w.planes_bytes && workspace_bytes >= w.total) p.planes = ws + w.off_planes, p.planes_bytes = w.planes_bytes;
 }
 
 // the reduction of the slab partials of one layer (shared by sow_backward_ex and the deferred, batched form)
@@ -243,8 +257,9 @@ int sow_reduce_batch(const void* descs, const int* starts, int n, int total_bloc
 size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0 || !ok_dtype(dtype)) return 0;
   const bool wide_acc = acc_kind == SOW_ACC_LOWRANK && r_acc > 64;
-  if (!wide_acc && short_hp_bytes(T, d_in, d_out, r_live, dtype) == 0) return 0;   // the forward does not touch it
-  return plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype).total + 256;
+  const WsPlan w = plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype);
+  if (!wide_acc && short_hp_bytes(T, d_in, d_out, r_live, dtype) == 0 && w.planes_bytes == 0) return 0;   // the forward does not touch it
+  return w.total + 256;
 }
 
 size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype) {
@@ -286,6 +301,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
       ph.M = T, ph.ldx = d_in, ph.ldy = d_out, ph.D1 = d_in, ph.D2 = 0;
       ph.F1b = A, ph.ldf1b = r_live, ph.F2b = B, ph.ldf2b = d_out, ph.rb = r_live;
       ph.scale = scale, ph.beta = 0.f;
+      set_planes(ph, ws, w, workspace_bytes);
       if (chain2_supported(ph, dtype) &&
           gemm2_supported(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, y, d_out, bias, T, d_out, d_in, dtype)) {
         // short T: the H-only pass split over K (T / 64 workgroups cannot fill the chip: 29 us on 16 workgroups at 1024 x 4096)
@@ -307,6 +323,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
       p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
       p.F1b = acc_down, p.ldf1b = r_acc, p.F2b = acc_up, p.ldf2b = d_out, p.rb = r_acc;
       p.scale = 1.f, p.beta = 0.f;
+      set_planes(p, ws, w, workspace_bytes);
       rc = launch_chain(p, dtype, false, stream);
       if (rc) return rc;
       beta = 1.f;
@@ -326,6 +343,7 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
     p.M = T, p.ldx = d_in, p.ldy = d_out, p.D1 = d_in, p.D2 = d_out;
     p.F1b = A, p.ldf1b = r_live, p.F2b = B, p.ldf2b = d_out, p.rb = r_live;
     p.scale = scale, p.beta = beta;
+    set_planes(p, ws, w, workspace_bytes);
     if (ws && workspace_bytes >= w.total) {
       rc = launch_chain_short(p, dtype, false, (float*)(ws + w.off_hp), stream);
       if (rc != SOW_ERR_UNSUPPORTED) return rc;
@@ -383,6 +401,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       pd.M = T, pd.ldx = d_out, pd.ldy = d_in, pd.D1 = d_out, pd.D2 = 0;
       pd.F1b = B, pd.ldf1b = d_out, pd.F2b = A, pd.ldf2b = r_live, pd.rb = r_live;
       pd.scale = scale, pd.beta = 0.f;
+      set_planes(pd, ws, w, workspace_bytes);
       void* apad = ws + w.off_apad;
       if (gemm4h_supported(dy, d_out, acc_down, d_out, true, B, d_out, A, r_live, dx, d_in, nullptr, dh, T, d_in, d_out, r_live,
                            dtype)) {
@@ -429,6 +448,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
       p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
       p.F1b = acc_up, p.ldf1b = d_out, p.F2b = acc_down, p.ldf2b = r_acc, p.rb = r_acc;
       p.scale = 1.f, p.beta = 0.f;
+      set_planes(p, ws, w, workspace_bytes);
       rc = launch_chain(p, dtype, true, stream);
       if (rc) return rc;
       beta = 1.f;
@@ -447,6 +467,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
     p.M = T, p.ldx = d_out, p.ldy = d_in, p.D1 = d_out, p.D2 = d_in;
     p.F1b = B, p.ldf1b = d_out, p.F2b = A, p.ldf2b = r_live, p.rb = r_live;
     p.scale = scale, p.beta = beta;
+    set_planes(p, ws, w, workspace_bytes);
     if (do_data && !data_done) {
       rc = launch_chain_short(p, dtype, true, short_hp_bytes(T, d_in, d_out, r_live, dtype) ? (float*)(ws + w.off_hp) : nullptr, stream);
       if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain(p, dtype, true, stream);

@@ -416,6 +416,10 @@ int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream) {
     const int rc = launch_chain2(p, bwd, stream);
     if (rc != SOW_ERR_ALIGN) return rc;  // factor alignment not met: fall through to the generic kernel
   }
+  if (chain3f_supported(p, dtype)) {
+    const int rc = launch_chain3f(p, bwd, stream);
+    if (rc != SOW_ERR_ALIGN) return rc;
+  }
   if (chain2f_supported(p, dtype) && !sw_on(SW_FORCE_CHAIN_V1)) {
     const int rc = launch_chain2f(p, bwd, stream);
     if (rc != SOW_ERR_ALIGN) return rc;

@@ -30,6 +30,10 @@ struct ChainParams {
   int nt_store;   // chain2: write Y with the non-temporal hint
   int nt_load;    // chain2 (experiment): stream X with the non-temporal hint
   int pair_flush; // chain2: store two output slices at a time (256-byte pieces per row)
+  // chain3f (fp32, T >= 8192): scratch for the pre-split factor planes (chain3f_plane_bytes(D1, D2), 16-byte aligned,
+  // from the caller's workspace); nullptr = not available, the launch falls back to chain2f
+  void* planes;
+  size_t planes_bytes;
 };
 int launch_chain(ChainParams p, int dtype, bool bwd, hipStream_t stream);
 // chain2.hip (bf16 streaming version)
@@ -50,6 +54,10 @@ int launch_h_reduce(const float* Hpartial, int nsplit, void* Hsave, int64_t M, i
 // chain2f.hip (fp32 streaming version)
 bool chain2f_supported(const ChainParams& p, int dtype);
 int launch_chain2f(const ChainParams& p, bool bwd, hipStream_t stream);
+// chain3f.hip (fp32 streaming version with pre-split factor planes, 128-token workgroups)
+size_t chain3f_plane_bytes(int d_in, int d_out);
+bool chain3f_supported(const ChainParams& p, int dtype);
+int launch_chain3f(const ChainParams& p, bool bwd, hipStream_t stream);
 // skinny_tn.hip
 struct TnJob {
   const void* M;

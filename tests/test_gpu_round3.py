@@ -373,3 +373,57 @@ def test_ttadam_sixteen_parameters_batched_equals_per_parameter():
     ma = oa.state[pa]["exp_avg"].to_matrix((512, 512))
     mb = ob.state[pb]["exp_avg"].to_matrix((512, 512))
     assert rel_err(ma.cpu(), mb.cpu()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# chain3f.hip: the fp32 streaming chain with pre-split factor planes (T >= 8192)
+C3F_CASES = [
+    # T, d_in, d_out, r, bias, scale, acc
+    (32768, 768, 768, 50, False, 1.0, None),       # BASELINE.json north_star point
+    (8192, 512, 1376, 50, True, 0.5, None),
+    (8200, 1376, 512, 50, False, 2.0, None),       # ragged last token block
+    (8192, 260, 132, 8, True, 1.0, None),          # widths not a multiple of 64, one rank tile
+    (9000, 64, 72, 33, True, 1.0, None),           # r just over one tile, ragged
+    (8192, 768, 768, 64, True, 1.0, None),         # r = 64: no free ones column (dbias by column sums)
+    (8192, 128, 64, 2, False, 1.0, None),
+    (8192, 256, 320, 16, True, 0.25, "lowrank"),   # low-rank accumulator: second chain launch with beta = 1
+    (8192, 768, 768, 8, True, 0.125, "dense"),     # config-4 style: fp32 dense accumulator + live rank 8
+]
+
+
+@pytest.mark.parametrize("case", C3F_CASES, ids=lambda c: "T%d_%dx%d_r%d%s" % (c[0], c[1], c[2], c[3], "_" + c[6] if c[6] else ""))
+def test_chain3f_fp32_vs_oracle(case):
+    """fp32 forward + backward at T >= 8192 (chain3f: factor planes split once per launch, 128-token workgroups, direct
+    row-segment stores) against the oracle, and against the chain2f path (NO_CHAIN3F) it replaces."""
+    from sow_amd import _lib, ops
+    T, d_in, d_out, r, has_bias, scale, acc = case
+    gen = torch.Generator(device=DEV).manual_seed(T + d_in + r)
+    x = torch.randn(T, d_in, generator=gen, device=DEV)
+    dy = torch.randn(T, d_out, generator=gen, device=DEV)
+    A = torch.randn(d_in, r, generator=gen, device=DEV) * 0.05
+    B = torch.randn(r, d_out, generator=gen, device=DEV) * 0.05
+    bias = torch.randn(d_out, generator=gen, device=DEV) * 0.1 if has_bias else None
+    acc_down = acc_up = None
+    if acc == "lowrank":
+        acc_down = torch.randn(d_in, 24, generator=gen, device=DEV) * 0.05
+        acc_up = torch.randn(24, d_out, generator=gen, device=DEV) * 0.05
+    elif acc == "dense":
+        acc_down = torch.randn(d_in, d_out, generator=gen, device=DEV) * 0.02
+    cpu = lambda t: None if t is None else t.cpu()
+
+    def run():
+        y, h = ops.sow_forward(x, A, B, acc_down, acc_up, bias, scale)
+        return (y,) + tuple(ops.sow_backward(dy, x, h, A, B, acc_down, acc_up, scale, has_bias))
+
+    new = run()
+    with _lib.switch(NO_CHAIN3F=1):
+        old = run()
+    y_ref = O.sow_forward(x.cpu(), [A.cpu()], [B.cpu()], cpu(acc_down), cpu(acc_up), scale, cpu(bias))
+    dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(dy.cpu(), x.cpu(), [A.cpu()], [B.cpu()], cpu(acc_down), cpu(acc_up), scale, has_bias)
+    refs = (y_ref, dx_ref, dA_ref[0], dB_ref[0], db_ref)
+    tols = (1e-5, 1e-5, 2e-5, 2e-5, 2e-5)   # weight gradients: T-term sums, summation order
+    for name, got, prev, ref, tol in zip(("y", "dx", "dA", "dB", "dbias"), new, old, refs, tols):
+        if ref is None:
+            continue
+        assert rel_err(got.cpu(), ref) < tol, name
+        assert rel_err(prev.cpu(), ref) < tol, name + " (chain2f)"
