@@ -55,7 +55,7 @@ const char* sow_error_string(int code);
 /* Kernel-selection switches -- for A/B measurements and for the tests that pin every kernel variant; production code
  * never touches them.  They are the library's ONLY process-wide state: a table of atomics initialised from the
  * environment (SOW_AMD_<NAME>) once, at first use; no launch path calls getenv.  Names: FORCE_CHAIN_V1, NO_SHORT_SPLIT,
- * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT, NO_PARK16, TN_NO_NT_LOAD, NO_TN_ROWS, NO_GEMM4H, NO_CHAIN3F
+ * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT, NO_PARK16, TN_NO_NT_LOAD, NO_TN_ROWS, NO_GEMM4H, NO_CHAIN3F, NO_TN_F32Q
  * (value 1 = on, -1 / 0 = off) and GEMM3S, GEMM3, GEMM4
  * (1 = force, 0 = forbid, -1 = automatic).  sow_set_switch returns SOW_ERR_UNSUPPORTED for an unknown name;
  * sow_get_switch returns the value (-1 / 0 / 1).  Changing a switch while other threads launch is safe (atomic) but

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
                                                    "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
-                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H",      "NO_CHAIN3F"};
+                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H",      "NO_CHAIN3F",     "NO_TN_F32Q"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -182,7 +182,8 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   off += short_hp_bytes(T, d_in, d_out, r_live, dtype);
   if (r_live <= 64) {
     const int cg_in = (d_in + 63) / 64, cg_out = (d_out + 63) / 64;
-    w.ns = tn_pick_slabs(T, cg_in + cg_out, (cg_in + 1) / 2 + (cg_out + 1) / 2, dtype, &w.slab_len);
+    const int quads = (dtype == SOW_F32 && tn_f32q_shape_ok(T, d_in, d_out)) ? (cg_in + 3) / 4 + (cg_out + 3) / 4 : 0;
+    w.ns = tn_pick_slabs(T, cg_in + cg_out, (cg_in + 1) / 2 + (cg_out + 1) / 2, quads, dtype, &w.slab_len);
     w.ns_cap = w.ns;
     if (dtype == SOW_BF16 && T >= 1024) {
       const int by_len = (int)(T / 512 < TNR_MAX_SLABS ? T / 512 : TNR_MAX_SLABS);

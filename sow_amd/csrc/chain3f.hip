@@ -70,12 +70,13 @@ __device__ __forceinline__ void split3_scalar(float x, uint32_t& h, uint32_t& m,
 // block c < nst: phase-1 image of chunk c, row = rank, position j = k c*64 + j;
 // block c >= nst: phase-2 image of slice c - nst, row = output column within the slice, position q = rank
 //   rho(q) = 16 (q >> 4) + 8 ((q >> 2) & 1) + 4 ((q >> 3) & 1) + (q & 3)   (the order H^T's accumulators hold them)
-__global__ __launch_bounds__(256) void chain3f_planes_kernel(const PlaneParams q) {
-  const int c = blockIdx.x;
+// (four blocks of 128 threads per image, one 16-byte piece of every plane per thread: the launch is a single chain of
+// gather -> split -> store, ~3 us, and sits on the critical path of the chain launch behind it)
+__global__ __launch_bounds__(128) void chain3f_planes_kernel(const PlaneParams q) {
+  const int c = blockIdx.x >> 2;
   char* img = q.out + (size_t)c * C4_FSLOT;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int item = threadIdx.x + 256 * it;
+  {
+    const int item = threadIdx.x + 128 * (blockIdx.x & 3);
     const int row = item >> 3, c16 = item & 7;
     u32x4 pl[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
@@ -422,7 +423,7 @@ int launch_chain3f(const ChainParams& p, bool bwd, hipStream_t stream) {
   q.Amat = (const float*)Ap, q.Bmat = (const float*)Bp, q.ldb = ldB;
   q.rb = p.rb, q.D1 = p.D1, q.D2 = p.D2, q.nst = nst, q.bwd = bwd ? 1 : 0;
   q.out = (char*)p.planes;
-  hipLaunchKernelGGL(chain3f_planes_kernel, dim3(nst + nsl), dim3(256), 0, stream, q);
+  hipLaunchKernelGGL(chain3f_planes_kernel, dim3(4 * (nst + nsl)), dim3(128), 0, stream, q);
   SOW_CHECK_LAUNCH();
   Chain3fParams k;
   k.X = (const float*)p.X, k.Y = (float*)p.Y, k.Hsave = (float*)p.Hsave, k.bias = (const float*)p.bias;

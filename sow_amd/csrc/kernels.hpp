@@ -95,8 +95,13 @@ struct ReduceParams {
   int blocks0;
 };
 // total_colgroups = 64-column groups over both jobs; total_colgroup_pairs = the same in pairs, rounded up per job
-int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len);
+// total_colgroup_quads > 0: the caller's shape takes the fp32 quad kernel (skinny_tn_f32q.hip: four column groups per block)
+int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int total_colgroup_quads, int dtype, int* slab_len);
+bool tn_f32q_shape_ok(int64_t T, int d_in, int d_out);
 size_t tn_partial_bytes(int ns, int D);
+// skinny_tn_f32q.hip
+bool tn_f32q_ok(const TnParams& p);
+int launch_tn_f32q(const TnParams& p, hipStream_t stream);
 int launch_tn(const TnParams& p, int dtype, hipStream_t stream);
 constexpr int TN_MAXG = 8;   // layers per grouped launch of the wide bf16 kernel (a decoder block has 7)
 struct TnGroup {

@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(256) void tn_reduce_batch_kernel(const ReduceParams
 }
 
 // ---------------------------------------------------------------------------------------------
-int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int dtype, int* slab_len) {
+int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int total_colgroup_quads, int dtype, int* slab_len) {
   const int bt = dtype == SOW_F32 ? TnCfg<float>::BT : TnCfg<bf16_t>::BT;
   // Two workgroups per CU are resident (64 KiB of LDS each), 512 in all; slabs stay >= 512 tokens so the
   // partial traffic (ns * D * 64 * 4 bytes) is a small fraction of the streamed operand.
@@ -1252,6 +1252,8 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
     // fp32 wide kernel: latency-bound on the bytes one CU keeps in flight (144 KiB of rings), so every CU counts:
     // no rounding to a multiple of 8 (d = 768: 21 slabs / 252 blocks instead of 16 / 192)
     if (dtype == SOW_F32) ns = 256 / cg2;
+    // fp32 quad kernel (skinny_tn_f32q.hip): four column groups per block, one 8-wave workgroup per CU, one round
+    if (dtype == SOW_F32 && total_colgroup_quads > 0) ns = 256 / total_colgroup_quads;
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
   }
@@ -1383,6 +1385,7 @@ int launch_tn(const TnParams& p, int dtype, hipStream_t stream) {
       dma = dma && J.D % 4 == 0 && J.ldm % 4 == 0 && (reinterpret_cast<uintptr_t>(J.M) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(J.S) & 15) == 0 && J.ones_col_in_s;
     }
+    if (dma && tn_f32q_ok(p)) return launch_tn_f32q(p, stream);
     if (dma && !sw_on(SW_F32_EXACT) && !sw_on(SW_TN_NARROW)) {
       constexpr int LDSW = TNFW_WAVES * TNFW_DEPTH * TNFW_STAGE_BYTES;  // 144 KiB
       int blocks2 = 0;   // two 64-column groups per block

@@ -1,0 +1,256 @@
+// fp32 weight-gradient partial sums, "quad" variant (3 x bf16 products, gfx950):  G[D, 64] = sum_t M[t, D]^T . S[t, 64]
+//
+// Same contract and partial-buffer layout as the kernels of skinny_tn.hip (dA = x^T . dh, dB^T = dY^T . h, dbias through the
+// all-ones column 63 of S; autograd of tn_gradient/layer/sow.py:117); a different work split.  The wide fp32 kernel there
+// gives a workgroup TWO 64-column groups and its own copy of the S stream: at d = 768 the h / dh rows are re-read (from L2)
+// six times per operand -- a third of everything the DMA path moves -- and every wave reads, splits and multiplies one
+// after the other (counters at the north-star point: matrix pipe 30 %, VALU 32 %, 6 waves on 4 SIMDs).  Here
+//   * a workgroup = 8 waves owns FOUR column groups (256 columns) of a token slab: wave (cg = w & 3, th = w >> 2) takes column
+//     group cg and the token half th of every 32-token stage -- the two waves of a SIMD work on the same columns, two k-steps
+//     apart -- so S is fetched once per 256 columns (3 x at d = 768) and shared through LDS;
+//   * a stage is 32 tokens: eight M images [16 tok][64 col] fp32 (one per wave, 4 DMA instructions each) and one S image
+//     [32 tok][64] (one instruction per wave), 40 KiB, three slots, one raw s_barrier per stage, counted vmcnt;
+//   * software pipeline across the barrier: after barrier i a wave issues the LDS reads of its k-step of stage i, then runs the
+//     24 MFMAs of stage i - 1 with the 3 x bf16 split of the new fragments (144 VALU) spread over the MFMA slots;
+//   * accumulators as in the wide kernel (lane li owns columns 2 li, 2 li + 1 of both operands' images); the two token halves
+//     are summed through LDS at the end of the slab, in a fixed order (deterministic).
+// Taken for fp32 inputs with T >= 4096 and at least 3 column groups per operand (tn_f32q_shape_ok); tn_pick_slabs then plans
+// the slab count for one resident round of these workgroups.
+#include "kernels.hpp"
+#include "lds_dma.hpp"
+
+namespace sow {
+
+constexpr int TN_BD = 64;            // columns per column group (as in skinny_tn.hip)
+constexpr int TNQ_WAVES = 8;
+constexpr int TNQ_DEPTH = 3;
+constexpr int TNQ_STAGE = 8 * 4096 + 8192;     // 40 KiB
+constexpr int TNQ_LDS = 147456;                // 144 KiB: three stages (120 KiB); the end-of-slab sum stages 8 x 16 KiB
+
+struct TnqFrag {
+  u32x4 mp[2][3];   // M^T fragments (column parity a), three planes
+  u32x4 sp[2][3];   // S fragments (column parity c)
+};
+
+__global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(const TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cg = w & 3, th = w >> 2;
+  int b = blockIdx.x, jid = 0;
+  const int nr0 = (p.job[0].ncg + 3) / 4;
+  if (p.njobs > 1 && b >= nr0 * p.ns) {
+    b -= nr0 * p.ns;
+    jid = 1;
+  }
+  const float* Mg = (const float*)(jid ? p.job[1].M : p.job[0].M);
+  const float* Sg = (const float*)(jid ? p.job[1].S : p.job[0].S);
+  float* Pg = jid ? p.job[1].partial : p.job[0].partial;
+  const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
+  const int D = jid ? p.job[1].D : p.job[0].D;
+  const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
+  const int range = b / p.ns, slab = b % p.ns;
+  const int g = range * 4 + cg;              // this wave's column group
+  const bool active = g < ncg;
+  const int d0 = g * TN_BD;
+  const int64_t t_begin = (int64_t)slab * p.slab_len;
+  int64_t t_end = t_begin + p.slab_len;
+  if (t_end > p.T) t_end = p.T;
+  const int nstage = t_begin < t_end ? (int)((t_end - t_begin + 31) / 32) : 0;
+  const char* zp = zero_page_for(lane);
+  const int drow = lane >> 4, dpc = lane & 15;
+
+  // per-lane DMA sources of stage 0: M instruction q = token rows 16 th + 4 q + drow, S instruction = rows 4 w + drow
+  const char* mptr[4];
+  const bool mcol_ok = active && d0 + dpc * 4 < D;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    mptr[q] = (const char*)(Mg + (t_begin + 16 * th + 4 * q + drow) * ldm + d0 + dpc * 4);
+  const char* sptr = (const char*)(Sg + (t_begin + 4 * w + drow) * 64 + dpc * 4);
+  const int64_t mstep = 32 * ldm * 4, sstep = 32 * 64 * 4;
+  // (a wave without a column group -- the tail of an operand's last range -- runs the same code on zeros: its SIMD has no
+  // other work, and the instruction stream stays free of wave-dependent branches around the asm reads)
+  auto issue = [&](int i) {   // strictly in order: the pointers are at stage i; 5 DMA instructions per wave and stage
+    const int64_t tt0 = t_begin + (int64_t)i * 32;
+    char* slot = smem + (i % TNQ_DEPTH) * TNQ_STAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const void* src = (mcol_ok && tt0 + 16 * th + 4 * q + drow < t_end) ? (const void*)mptr[q] : (const void*)zp;
+      dma16(src, slot + w * 4096 + q * 1024);
+      mptr[q] += mstep;
+    }
+    {
+      const void* src = (tt0 + 4 * w + drow < t_end) ? (const void*)sptr : (const void*)zp;
+      dma16(src, slot + 8 * 4096 + w * 1024);
+      sptr += sstep;
+    }
+  };
+
+  f32x16 acc[2][2];   // [M column parity a][S column parity c]: register reg of lane l = G[2 * acc_row(reg, l) + a][2 * (l & 31) + c]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const uint32_t lds0 = lds_addr(smem);
+  // lane-half lh reads tokens 8 lh .. 8 lh + 7 of the wave's 16: one ds_read_b64 per token (columns 2 li, 2 li + 1)
+  const uint32_t moff = (uint32_t)(w * 4096 + lh * 2048 + li * 8);
+  const uint32_t soff = (uint32_t)(8 * 4096 + th * 4096 + lh * 2048 + li * 8);
+
+  TnqFrag FA, FB;
+  f32x2 sv[8], mv[8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) FA.mp[a][pl] = FA.sp[a][pl] = FB.mp[a][pl] = FB.sp[a][pl] = (u32x4){0, 0, 0, 0};
+
+#define TNQ_READ(i_)                                                                   \
+  do {                                                                                 \
+    const uint32_t sa__ = lds0 + (uint32_t)(((i_) % TNQ_DEPTH) * TNQ_STAGE);           \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) DS_READ_B64(sv[j__], sa__ + soff, j__ * 256); \
+    _Pragma("unroll") for (int j__ = 0; j__ < 8; ++j__) DS_READ_B64(mv[j__], sa__ + moff, j__ * 256); \
+  } while (0)
+  // all 16 reads of the latest TNQ_READ have landed (the registers go through the wait: no consumer can move above it)
+#define TNQ_WAIT()                                                                                                      \
+  do {                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                 : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]), \
+                   "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]), "+v"(mv[4]), "+v"(mv[5]), "+v"(mv[6]), "+v"(mv[7]) \
+                 :                                                                                                      \
+                 : "memory");                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  } while (0)
+  // split pair pr of the fresh fragments into NXT: items 0-7 = S (parity c = item >> 2), 8-15 = M (parity a)
+#define TNQ_SPLIT(NXT, it_)                                                                              \
+  do {                                                                                                   \
+    constexpr int it__ = (it_);                                                                          \
+    constexpr int par__ = (it__ >> 2) & 1, pr__ = it__ & 3;                                              \
+    if constexpr (it__ < 8) split3v(sv[2 * pr__][par__], sv[2 * pr__ + 1][par__], NXT.sp[par__], pr__); \
+    else split3v(mv[2 * pr__][par__], mv[2 * pr__ + 1][par__], NXT.mp[par__], pr__);                     \
+  } while (0)
+  // the 24 MFMAs of fragment CUR; with FILL, the 16 split items of the fresh reads are spread over MFMA slots 3 .. 23
+#define TNQ_MF(CUR, i_)                                                                                              \
+  do {                                                                                                               \
+    constexpr int i__ = (i_);                                                                                        \
+    constexpr int a__ = i__ / 12, c__ = (i__ / 6) & 1, k__ = i__ % 6;                                                \
+    constexpr int ia__[6] = {2, 0, 1, 1, 0, 0}, ib__[6] = {0, 2, 1, 0, 1, 0};                                        \
+    acc[a__][c__] = mfma32(as_bf16x8(CUR.mp[a__][ia__[k__]]), as_bf16x8(CUR.sp[c__][ib__[k__]]), acc[a__][c__]);     \
+  } while (0)
+#define TNQ_STEP(CUR, NXT, FILL)                                                                         \
+  do {                                                                                                   \
+    TNQ_MF(CUR, 0); __builtin_amdgcn_sched_barrier(0);                                                   \
+    TNQ_MF(CUR, 1); __builtin_amdgcn_sched_barrier(0);                                                   \
+    TNQ_MF(CUR, 2); if (FILL) TNQ_WAIT(); __builtin_amdgcn_sched_barrier(0);                             \
+    TNQ_MF(CUR, 3); if (FILL) TNQ_SPLIT(NXT, 0); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 4); if (FILL) TNQ_SPLIT(NXT, 1); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 5); if (FILL) TNQ_SPLIT(NXT, 2); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 6); __builtin_amdgcn_sched_barrier(0);                                                   \
+    TNQ_MF(CUR, 7); if (FILL) TNQ_SPLIT(NXT, 3); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 8); if (FILL) TNQ_SPLIT(NXT, 4); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 9); if (FILL) TNQ_SPLIT(NXT, 5); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 10); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 11); if (FILL) TNQ_SPLIT(NXT, 6); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 12); if (FILL) TNQ_SPLIT(NXT, 7); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 13); if (FILL) TNQ_SPLIT(NXT, 8); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 14); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 15); if (FILL) TNQ_SPLIT(NXT, 9); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 16); if (FILL) TNQ_SPLIT(NXT, 10); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 17); if (FILL) TNQ_SPLIT(NXT, 11); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 18); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 19); if (FILL) TNQ_SPLIT(NXT, 12); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 20); if (FILL) TNQ_SPLIT(NXT, 13); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 21); if (FILL) TNQ_SPLIT(NXT, 14); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 22); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 23); if (FILL) TNQ_SPLIT(NXT, 15); __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+  // stage i: wait for this wave's DMA, barrier, refill the ring, read the fresh fragments, multiply the previous ones
+#define TNQ_ITER(i_, CUR, NXT)                                                                           \
+  do {                                                                                                   \
+    const int newer__ = (nstage - 1 - (i_)) < (TNQ_DEPTH - 2) ? (nstage - 1 - (i_)) : (TNQ_DEPTH - 2);   \
+    if (newer__ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    raw_barrier();                                                                                       \
+    if ((i_) + TNQ_DEPTH - 1 < nstage) issue((i_) + TNQ_DEPTH - 1);                                      \
+    TNQ_READ(i_);                                                                                        \
+    TNQ_STEP(CUR, NXT, true);                                                                            \
+  } while (0)
+
+  const int pre = nstage < TNQ_DEPTH - 1 ? nstage : TNQ_DEPTH - 1;
+  for (int i = 0; i < pre; ++i) issue(i);
+  int i = 0;
+#pragma unroll 1
+  for (; i + 1 < nstage; i += 2) {
+    TNQ_ITER(i, FA, FB);       // FA holds stage i - 1 (zeros before the first stage), FB receives stage i
+    TNQ_ITER(i + 1, FB, FA);
+  }
+  if (i < nstage) {
+    TNQ_ITER(i, FA, FB);
+    TNQ_STEP(FB, FA, false);
+  } else {
+    TNQ_STEP(FA, FB, false);
+  }
+#undef TNQ_ITER
+#undef TNQ_STEP
+#undef TNQ_MF
+#undef TNQ_SPLIT
+#undef TNQ_WAIT
+#undef TNQ_READ
+
+  // ------------------------------------------------------------------ end of slab: sum the two token halves, store
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  raw_barrier();   // every wave is done with the rings
+  float* red = (float*)smem + w * 4096;   // [64][64] fp32 per wave
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) red[(2 * acc_row(reg, lane) + a) * 64 + 2 * li + c] = acc[a][c][reg];
+  __syncthreads();
+  const float* redall = (const float*)smem;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int v = t + 64 * TNQ_WAVES * k;   // 4 tiles x 1024 float4
+    const int tile = v >> 10, e = v & 1023;
+    const int gg = range * 4 + tile;
+    if (gg < ncg) {
+      const f32x4 s0 = *(const f32x4*)(redall + tile * 4096 + e * 4);
+      const f32x4 s1 = *(const f32x4*)(redall + (tile + 4) * 4096 + e * 4);
+      float* P = Pg + ((int64_t)slab * ncg * TN_BD + (int64_t)gg * TN_BD) * 64;
+      *(f32x4*)(P + e * 4) = s0 + s1;
+    }
+  }
+}
+
+// shapes the quad kernel is planned for (tn_pick_slabs) -- alignment is checked at launch
+bool tn_f32q_shape_ok(int64_t T, int d_in, int d_out) {
+  if (sw_on(SW_F32_EXACT) || sw_on(SW_TN_NARROW) || sw_on(SW_NO_TN_F32Q)) return false;
+  return T >= 4096 && (d_in + 63) / 64 >= 3 && (d_out + 63) / 64 >= 3;
+}
+
+bool tn_f32q_ok(const TnParams& p) {
+  if (p.njobs != 2 || p.slab_len % 32 || p.ns < 1) return false;
+  if (!tn_f32q_shape_ok(p.T, p.job[0].D, p.job[1].D)) return false;
+  for (int j = 0; j < p.njobs; ++j) {
+    const TnJob& J = p.job[j];
+    if (J.D % 4 || J.ldm % 4 || (reinterpret_cast<uintptr_t>(J.M) & 15) || (reinterpret_cast<uintptr_t>(J.S) & 15) || !J.ones_col_in_s)
+      return false;
+  }
+  return true;
+}
+
+int launch_tn_f32q(const TnParams& p, hipStream_t stream) {
+  int blocks = 0;
+  for (int j = 0; j < p.njobs; ++j) blocks += (p.job[j].ncg + 3) / 4 * p.ns;
+  if (blocks <= 0) return SOW_OK;
+  SOW_SET_MAX_LDS_ONCE(TNQ_LDS, tn_partial_f32_quad_kernel);
+  hipLaunchKernelGGL(tn_partial_f32_quad_kernel, dim3(blocks), dim3(64 * TNQ_WAVES), TNQ_LDS, stream, p);
+  SOW_CHECK_LAUNCH();
+  return SOW_OK;
+}
+
+}  // namespace sow
