@@ -27,6 +27,34 @@ constexpr int TNQ_DEPTH = 3;
 constexpr int TNQ_STAGE = 8 * 4096 + 8192;     // 40 KiB
 constexpr int TNQ_LDS = 147456;                // 144 KiB: three stages (120 KiB); the end-of-slab sum stages 8 x 16 KiB
 
+// 3 x bf16 split of one fragment read as eight ds_read_b64 (token j -> the lane's two columns): the two exact residual
+// subtractions run on the (column 0, column 1) pair of each token -- the registers a b64 read delivers together -- and the
+// v_perm_b32 that packs two tokens' high halves into one dword picks its operands freely, so no register moves are needed
+// (pairing consecutive tokens of ONE column, as split3v does, costs two v_mov per pair here).
+// (Integer-typed registers on purpose: hipcc 7.2 folds element 1 of a FLOAT vector into element 0 when the elements are
+// bit-cast -- lds_dma.hpp -- and did so here with f32x2 fragments: both columns of the residual came from column 0.)
+__device__ __forceinline__ void tnq_residuals(const u32x2 v, uint64_t& x64, uint64_t& r64, uint64_t& q64) {
+  constexpr uint32_t MK = 0xffff0000u;
+  const uint32_t u0 = v[0], u1 = v[1];
+  x64 = (uint64_t)u0 | ((uint64_t)u1 << 32);
+  r64 = pk_sub_f32(x64, (uint64_t)(u0 & MK) | ((uint64_t)(u1 & MK) << 32));
+  const uint32_t r0 = (uint32_t)r64, r1 = (uint32_t)(r64 >> 32);
+  q64 = pk_sub_f32(r64, (uint64_t)(r0 & MK) | ((uint64_t)(r1 & MK) << 32));
+}
+// tokens 2 pr, 2 pr + 1 of both columns -> element pr of the six plane vectors
+__device__ __forceinline__ void tnq_split_pair(const u32x2 va, const u32x2 vb, u32x4 (&p0)[3], u32x4 (&p1)[3], int pr) {
+  constexpr uint32_t HI = 0x07060302u;   // v_perm_b32(b, a, HI) = (a >> 16) | (b & 0xffff0000)
+  uint64_t xa, ra, qa, xb, rb, qb;
+  tnq_residuals(va, xa, ra, qa);
+  tnq_residuals(vb, xb, rb, qb);
+  p0[0][pr] = __builtin_amdgcn_perm((uint32_t)xb, (uint32_t)xa, HI);
+  p1[0][pr] = __builtin_amdgcn_perm((uint32_t)(xb >> 32), (uint32_t)(xa >> 32), HI);
+  p0[1][pr] = __builtin_amdgcn_perm((uint32_t)rb, (uint32_t)ra, HI);
+  p1[1][pr] = __builtin_amdgcn_perm((uint32_t)(rb >> 32), (uint32_t)(ra >> 32), HI);
+  p0[2][pr] = __builtin_amdgcn_perm((uint32_t)qb, (uint32_t)qa, HI);
+  p1[2][pr] = __builtin_amdgcn_perm((uint32_t)(qb >> 32), (uint32_t)(qa >> 32), HI);
+}
+
 struct TnqFrag {
   u32x4 mp[2][3];   // M^T fragments (column parity a), three planes
   u32x4 sp[2][3];   // S fragments (column parity c)
@@ -101,7 +129,7 @@ __global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(
   const uint32_t soff = (uint32_t)(8 * 4096 + th * 4096 + lh * 2048 + li * 8);
 
   TnqFrag FA, FB;
-  f32x2 sv[8], mv[8];
+  u32x2 sv[8], mv[8];   // raw fp32 bit patterns: token j -> (column 2 li, column 2 li + 1)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -123,15 +151,15 @@ __global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(
                  : "memory");                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   } while (0)
-  // split pair pr of the fresh fragments into NXT: items 0-7 = S (parity c = item >> 2), 8-15 = M (parity a)
+  // split item it of the fresh fragments into NXT: items 0-3 = token pairs of S, 4-7 = of M (both column parities at once)
 #define TNQ_SPLIT(NXT, it_)                                                                              \
   do {                                                                                                   \
     constexpr int it__ = (it_);                                                                          \
-    constexpr int par__ = (it__ >> 2) & 1, pr__ = it__ & 3;                                              \
-    if constexpr (it__ < 8) split3v(sv[2 * pr__][par__], sv[2 * pr__ + 1][par__], NXT.sp[par__], pr__); \
-    else split3v(mv[2 * pr__][par__], mv[2 * pr__ + 1][par__], NXT.mp[par__], pr__);                     \
+    constexpr int pr__ = it__ & 3;                                                                       \
+    if constexpr (it__ < 4) tnq_split_pair(sv[2 * pr__], sv[2 * pr__ + 1], NXT.sp[0], NXT.sp[1], pr__);  \
+    else tnq_split_pair(mv[2 * pr__], mv[2 * pr__ + 1], NXT.mp[0], NXT.mp[1], pr__);                     \
   } while (0)
-  // the 24 MFMAs of fragment CUR; with FILL, the 16 split items of the fresh reads are spread over MFMA slots 3 .. 23
+  // the 24 MFMAs of fragment CUR; with FILL, the 8 split items of the fresh reads are spread over MFMA slots 3 .. 21
 #define TNQ_MF(CUR, i_)                                                                                              \
   do {                                                                                                               \
     constexpr int i__ = (i_);                                                                                        \
@@ -145,26 +173,26 @@ __global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(
     TNQ_MF(CUR, 1); __builtin_amdgcn_sched_barrier(0);                                                   \
     TNQ_MF(CUR, 2); if (FILL) TNQ_WAIT(); __builtin_amdgcn_sched_barrier(0);                             \
     TNQ_MF(CUR, 3); if (FILL) TNQ_SPLIT(NXT, 0); __builtin_amdgcn_sched_barrier(0);                      \
-    TNQ_MF(CUR, 4); if (FILL) TNQ_SPLIT(NXT, 1); __builtin_amdgcn_sched_barrier(0);                      \
-    TNQ_MF(CUR, 5); if (FILL) TNQ_SPLIT(NXT, 2); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 4); __builtin_amdgcn_sched_barrier(0);                                                   \
+    TNQ_MF(CUR, 5); if (FILL) TNQ_SPLIT(NXT, 1); __builtin_amdgcn_sched_barrier(0);                      \
     TNQ_MF(CUR, 6); __builtin_amdgcn_sched_barrier(0);                                                   \
-    TNQ_MF(CUR, 7); if (FILL) TNQ_SPLIT(NXT, 3); __builtin_amdgcn_sched_barrier(0);                      \
-    TNQ_MF(CUR, 8); if (FILL) TNQ_SPLIT(NXT, 4); __builtin_amdgcn_sched_barrier(0);                      \
-    TNQ_MF(CUR, 9); if (FILL) TNQ_SPLIT(NXT, 5); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 7); __builtin_amdgcn_sched_barrier(0);                                                   \
+    TNQ_MF(CUR, 8); if (FILL) TNQ_SPLIT(NXT, 2); __builtin_amdgcn_sched_barrier(0);                      \
+    TNQ_MF(CUR, 9); __builtin_amdgcn_sched_barrier(0);                                                   \
     TNQ_MF(CUR, 10); __builtin_amdgcn_sched_barrier(0);                                                  \
-    TNQ_MF(CUR, 11); if (FILL) TNQ_SPLIT(NXT, 6); __builtin_amdgcn_sched_barrier(0);                     \
-    TNQ_MF(CUR, 12); if (FILL) TNQ_SPLIT(NXT, 7); __builtin_amdgcn_sched_barrier(0);                     \
-    TNQ_MF(CUR, 13); if (FILL) TNQ_SPLIT(NXT, 8); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 11); if (FILL) TNQ_SPLIT(NXT, 3); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 12); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 13); if (FILL) TNQ_SPLIT(NXT, 4); __builtin_amdgcn_sched_barrier(0);                     \
     TNQ_MF(CUR, 14); __builtin_amdgcn_sched_barrier(0);                                                  \
-    TNQ_MF(CUR, 15); if (FILL) TNQ_SPLIT(NXT, 9); __builtin_amdgcn_sched_barrier(0);                     \
-    TNQ_MF(CUR, 16); if (FILL) TNQ_SPLIT(NXT, 10); __builtin_amdgcn_sched_barrier(0);                    \
-    TNQ_MF(CUR, 17); if (FILL) TNQ_SPLIT(NXT, 11); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 15); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 16); if (FILL) TNQ_SPLIT(NXT, 5); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 17); __builtin_amdgcn_sched_barrier(0);                                                  \
     TNQ_MF(CUR, 18); __builtin_amdgcn_sched_barrier(0);                                                  \
-    TNQ_MF(CUR, 19); if (FILL) TNQ_SPLIT(NXT, 12); __builtin_amdgcn_sched_barrier(0);                    \
-    TNQ_MF(CUR, 20); if (FILL) TNQ_SPLIT(NXT, 13); __builtin_amdgcn_sched_barrier(0);                    \
-    TNQ_MF(CUR, 21); if (FILL) TNQ_SPLIT(NXT, 14); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 19); if (FILL) TNQ_SPLIT(NXT, 6); __builtin_amdgcn_sched_barrier(0);                     \
+    TNQ_MF(CUR, 20); __builtin_amdgcn_sched_barrier(0);                                                  \
+    TNQ_MF(CUR, 21); if (FILL) TNQ_SPLIT(NXT, 7); __builtin_amdgcn_sched_barrier(0);                     \
     TNQ_MF(CUR, 22); __builtin_amdgcn_sched_barrier(0);                                                  \
-    TNQ_MF(CUR, 23); if (FILL) TNQ_SPLIT(NXT, 15); __builtin_amdgcn_sched_barrier(0);                    \
+    TNQ_MF(CUR, 23); __builtin_amdgcn_sched_barrier(0);                                                  \
   } while (0)
   // stage i: wait for this wave's DMA, barrier, refill the ring, read the fresh fragments, multiply the previous ones
 #define TNQ_ITER(i_, CUR, NXT)                                                                           \
