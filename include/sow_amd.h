@@ -55,7 +55,7 @@ const char* sow_error_string(int code);
 /* Kernel-selection switches -- for A/B measurements and for the tests that pin every kernel variant; production code
  * never touches them.  They are the library's ONLY process-wide state: a table of atomics initialised from the
  * environment (SOW_AMD_<NAME>) once, at first use; no launch path calls getenv.  Names: FORCE_CHAIN_V1, NO_SHORT_SPLIT,
- * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT, NO_PARK16, TN_NO_NT_LOAD, NO_TN_ROWS, NO_GEMM4H, NO_CHAIN3F, NO_TN_F32Q
+ * NO_FUSED_H, FORCE_GEMM_V1, TN_NARROW, NO_GEMM3S, NO_GROUPED, NO_PERSIST, NO_NT_STORE, NT_LOAD, NO_PAIR_FLUSH, F32_EXACT, NO_PARK16, TN_NO_NT_LOAD, NO_TN_ROWS, NO_GEMM4H, NO_CHAIN3F, NO_TN_F32Q, NO_SPLITK
  * (value 1 = on, -1 / 0 = off) and GEMM3S, GEMM3, GEMM4
  * (1 = force, 0 = forbid, -1 = automatic).  sow_set_switch returns SOW_ERR_UNSUPPORTED for an unknown name;
  * sow_get_switch returns the value (-1 / 0 / 1).  Changing a switch while other threads launch is safe (atomic) but
@@ -180,6 +180,15 @@ int sow_backward_group_plan(const sow_layer_args* layers, int n, int dtype, int 
  * sites: accumulate() sow.py:131-140 (W_acc += scale * A @ B, Q @ R), prepare.py:135, tt.py:213-237. */
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
              const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream);
+
+/* The same with scratch for the caller's stream: short bf16 products (M <= ~1024 rows of a wide output: fewer output tiles
+ * than the chip has CUs) are split over K across workgroups, fp32 partial sums through `workspace`, summed in a fixed
+ * order.  sow_gemm_workspace_bytes returns 0 when the shape does not split (workspace may then be NULL); sow_gemm is
+ * sow_gemm_ex without scratch. */
+size_t sow_gemm_workspace_bytes(int64_t M, int N, int K, int trans_a, int dtype);
+int sow_gemm_ex(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
+                const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* Truncated Householder QR -- replaces qr_weight (utils.py:8-30) and the truncated complete-mode QR
  * of TensorTrain.decompose (tt.py:128-136):  Q_out[m,k] = Q[:, :k], R_out[k,n] = R[:k, :]

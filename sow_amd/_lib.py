@@ -82,6 +82,9 @@ SIGNATURES = {
     "sow_reduce_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sow_gemm": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
                          c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "sow_gemm_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "sow_gemm_ex": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                            c_int, c_int, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "sow_qr_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "sow_qr_thin": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
                             c_void_p, c_size_t, c_void_p]),

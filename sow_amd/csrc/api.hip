@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* M, int64_t ld, int
 namespace sow {
 static const char* const kSwitchNames[SW_COUNT] = {"FORCE_CHAIN_V1", "NO_SHORT_SPLIT", "NO_FUSED_H", "FORCE_GEMM_V1", "TN_NARROW",
                                                    "NO_GEMM3S",      "GEMM3S",         "GEMM3",      "NO_GROUPED",     "NO_PERSIST",     "NO_NT_STORE",    "NT_LOAD",        "NO_PAIR_FLUSH",  "F32_EXACT",
-                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H",      "NO_CHAIN3F",     "NO_TN_F32Q"};
+                                                   "NO_PARK16",      "TN_NO_NT_LOAD",  "NO_TN_ROWS",     "GEMM4",          "NO_GEMM4H",      "NO_CHAIN3F",     "NO_TN_F32Q",     "NO_SPLITK"};
 static std::atomic<int> g_switch[SW_COUNT];
 static std::once_flag g_switch_once;
 static void switches_from_env() {
@@ -110,9 +110,10 @@ static int launch_chain_short(const ChainParams& p, int dtype, bool bwd, float* 
 
 // row-major A, plain product: the streaming kernel when it fills the chip, else the 128x128 kernel
 static int gemm_auto(const void* A, int64_t lda, const void* B, int64_t ldb, bool transB, void* C, int64_t ldc,
-                     const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream) {
+                     const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, hipStream_t stream,
+                     void* ws = nullptr, size_t ws_bytes = 0) {
   if (gemm2_supported(A, lda, B, ldb, transB, nullptr, 0, nullptr, 0, C, ldc, bias, M, N, K, dtype))
-    return launch_gemm2(A, lda, B, ldb, transB, nullptr, 0, nullptr, 0, 0, C, ldc, bias, M, N, K, alpha, beta, stream);
+    return launch_gemm2(A, lda, B, ldb, transB, nullptr, 0, nullptr, 0, 0, C, ldc, bias, M, N, K, alpha, beta, stream, ws, ws_bytes);
   return launch_gemm(A, lda, false, B, ldb, transB, C, ldc, bias, M, N, K, alpha, beta, dtype, stream);
 }
 
@@ -163,7 +164,7 @@ size_t sow_h_save_elems(int64_t T, int r_live) { return (size_t)T * (size_t)(r_l
 
 // workspace carve (identical in the query and in the calls)
 struct WsPlan {
-  size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, off_planes, planes_bytes, total;
+  size_t off_dh, off_t, off_apad, off_hp, off_p0, off_p1, off_planes, planes_bytes, off_sk, sk_bytes, total;
   int ns, slab_len;
   int ns_cap;   // slabs the partial regions can hold (group-planned slab counts may exceed the single-layer choice)
 };
@@ -201,6 +202,15 @@ static WsPlan plan_ws(int64_t T, int d_in, int d_out, int r_live, int r_acc, int
   if (dtype == SOW_F32 && T >= C3F_MIN_T && (r_live <= 64 || (acc_kind == SOW_ACC_LOWRANK && r_acc <= 64))) {
     w.planes_bytes = chain3f_plane_bytes(d_in, d_out);
     off += al256(w.planes_bytes);
+  }
+  // split-K scratch of the dense-accumulator products of short inputs (gemm4.hip): forward [T, d_out] over K = d_in (+ the
+  // rank extension), backward [T, d_in] over K = d_out
+  w.off_sk = off;
+  w.sk_bytes = 0;
+  if (dtype == SOW_BF16 && acc_kind == SOW_ACC_DENSE) {
+    const size_t f = gemm4_splitk_bytes(T, d_out, d_in, true), b = gemm4_splitk_bytes(T, d_in, d_out, true);
+    w.sk_bytes = f > b ? f : b;
+    off += al256(w.sk_bytes);
   }
   w.total = off;
   return w;
@@ -259,7 +269,7 @@ size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, i
   if (T < 0 || d_in <= 0 || d_out <= 0 || r_live <= 0 || !ok_dtype(dtype)) return 0;
   const bool wide_acc = acc_kind == SOW_ACC_LOWRANK && r_acc > 64;
   const WsPlan w = plan_ws(T, d_in, d_out, r_live, r_acc, acc_kind, dtype);
-  if (!wide_acc && short_hp_bytes(T, d_in, d_out, r_live, dtype) == 0 && w.planes_bytes == 0) return 0;   // the forward does not touch it
+  if (!wide_acc && short_hp_bytes(T, d_in, d_out, r_live, dtype) == 0 && w.planes_bytes == 0 && w.sk_bytes == 0) return 0;   // the forward does not touch it
   return w.total + 256;
 }
 
@@ -310,8 +320,9 @@ int sow_forward(const void* x, const void* A, const void* B, const void* acc_dow
         if (ws && workspace_bytes >= w.total) rc = launch_chain_short(ph, dtype, false, (float*)(ws + w.off_hp), stream);
         if (rc == SOW_ERR_UNSUPPORTED) rc = launch_chain2(ph, false, stream);
         if (rc) return rc;
+        const bool sk = ws && w.sk_bytes && workspace_bytes >= w.total;
         return launch_gemm2(x, d_in, acc_down, d_out, false, h_save, 64, B, d_out, r_live, y, d_out, bias, T, d_out, d_in,
-                            1.f, 0.f, stream);
+                            1.f, 0.f, stream, sk ? ws + w.off_sk : nullptr, sk ? w.sk_bytes : 0);
       }
     }
     rc = gemm_auto(x, d_in, acc_down, d_out, false, y, d_out, nullptr, T, d_out, d_in, 1.f, 0.f, dtype, stream);
@@ -432,7 +443,7 @@ int sow_backward_ex(const void* dy, const void* x, const void* h_save, const voi
           if (rc) return rc;
         }
         rc = launch_gemm2(dy, d_out, acc_down, d_out, true, dh, 64, apad, 64, 64, dx, d_in, nullptr, T, d_in, d_out, 1.f, 0.f,
-                          stream);
+                          stream, w.sk_bytes ? ws + w.off_sk : nullptr, w.sk_bytes);
         if (rc) return rc;
         data_done = true;
       }
@@ -822,7 +833,20 @@ int sow_backward_group_reduce_desc(const sow_layer_args* layers, int n, int dtyp
 
 int sow_gemm(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
              const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* stream) {
-  if (!trans_a) return gemm_auto(A, lda, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
+  return sow_gemm_ex(A, lda, trans_a, B, ldb, trans_b, C, ldc, bias, M, N, K, alpha, beta, dtype, nullptr, 0, stream);
+}
+
+size_t sow_gemm_workspace_bytes(int64_t M, int N, int K, int trans_a, int dtype) {
+  if (trans_a || dtype != SOW_BF16 || M <= 0 || N <= 0 || K <= 0) return 0;
+  return gemm4_splitk_bytes(M, N, K, false);
+}
+
+int sow_gemm_ex(const void* A, int64_t lda, int trans_a, const void* B, int64_t ldb, int trans_b, void* C, int64_t ldc,
+                const void* bias, int64_t M, int N, int K, float alpha, float beta, int dtype, void* workspace,
+                size_t workspace_bytes, void* stream) {
+  if (!trans_a)
+    return gemm_auto(A, lda, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream, workspace,
+                     workspace_bytes);
   return launch_gemm(A, lda, trans_a != 0, B, ldb, trans_b != 0, C, ldc, bias, M, N, K, alpha, beta, dtype, (hipStream_t)stream);
 }
 

@@ -142,6 +142,7 @@ enum Switch : int {
   SW_NO_GEMM4H,           // dense-accumulator layer with the projection inside the kernel: gemm2h instead of gemm4h
   SW_NO_CHAIN3F,          // fp32 chain: chain2f (per-use factor split, 64-token workgroups) instead of chain3f
   SW_NO_TN_F32Q,          // fp32 weight gradients: the wide (two column groups, private S stream) kernel instead of the quad one
+  SW_NO_SPLITK,           // bf16 GEMM with few output tiles (short T): never split K over workgroups
   SW_COUNT
 };
 int sw(int which);

@@ -258,7 +258,7 @@ bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
 
 int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
-                 float alpha, float beta, hipStream_t stream) {
+                 float alpha, float beta, hipStream_t stream, void* ws, size_t ws_bytes) {
   Gemm2Params p;
   p.A = (const bf16_t*)A, p.B = (const bf16_t*)B, p.A2 = (const bf16_t*)A2, p.B2 = (const bf16_t*)B2;
   p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias;
@@ -272,10 +272,13 @@ int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   // fill at least half of the chip (profiles/r03_gemm4_vs_round2_vs_hipblaslt.txt: 4096^3 1.38 vs 0.97-1.03 PF, 32768 x 512
   // -> 1376 58 vs 72 us); with fewer tiles (M = 1024 x N = 4096: 64) the 128 x 128 tiles of gemm3s fill more CUs.
   // GEMM4 = 1 forces it on every supported shape, 0 forbids it.
+  // With scratch from the caller, short products (<= 128 tiles, long K) run gemm4 split over K: M = 1024 x N = 4096 as 64 tiles
+  // x 4 splits instead of gemm3s's 256 small tiles.
   const int g4 = sw(SW_GEMM4);
-  if ((g4 > 0 || (g4 < 0 && tiles >= 120 && K >= 64)) &&
+  const int64_t work = tiles * gemm4_splits(M, N, K, A2 != nullptr, ws, ws_bytes);
+  if ((g4 > 0 || (g4 < 0 && work >= 120 && K >= 64)) &&
       gemm4_supported(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, C, ldc, bias, M, N, K, SOW_BF16))
-    return launch_gemm4(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);
+    return launch_gemm4(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream, ws, ws_bytes);
   const int gs = sw(SW_GEMM3S);
   if (gs >= 0 ? gs != 0 : ((int64_t)ceil_div(M, G2_BM) * ceil_div(N, G2_BN) < 160))
     return launch_gemm3s(A, lda, B, ldb, nt, A2, lda2, B2, ldb2, k2, C, ldc, bias, M, N, K, alpha, beta, stream);

@@ -27,7 +27,9 @@
 //     16-byte writes and stores whole 128-byte row segments;
 //   * per-lane source pointers for the eight DMA instructions of a K-tile are carried in registers and advanced by one
 //     64-bit add; rows / columns beyond the matrix are CLAMPED (they only feed outputs that are never stored); the K tail
-//     and the extension tile take a checked path that reads the zero page where k is out of range.
+//     and the extension tile take a checked path that reads the zero page where k is out of range;
+//   * short M (config 5: T = 1024 -> 64 tiles for a 4096-wide output) runs split-K: S blocks per tile, each on a K range,
+//     fp32 partials through the caller's workspace, the last split sums them in a fixed order (see Gemm4Params).
 #include "kernels.hpp"
 #include "lds_dma.hpp"
 #include <type_traits>
@@ -66,6 +68,14 @@ struct Gemm4Params {
   bf16_t* Hout;
   int r;
   float hscale;
+  // split-K (short M: fewer output tiles than CUs).  splits > 1: block b = split * tiles + tile runs K-tiles
+  // [split * kt_per, ...) of its tile; splits 0 .. S-2 leave their fp32 accumulators in `partials` ([tile][split][32][512]
+  // float4: register quad q of thread t) and raise flags[tile * (S - 1) + split]; the LAST split -- the highest block ids,
+  // dispatched after its partners -- waits for them, adds the partials in split order (deterministic) and runs the epilogue.
+  // flags are zeroed by the launcher (hipMemsetAsync ahead of the kernel).
+  int splits, kt_per;
+  float* partials;
+  int* flags;
 };
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
@@ -115,22 +125,30 @@ template <int KIND> __device__ __forceinline__ constexpr int g4_slot_off() {
   return KIND == G4_A0 ? G4_OFF_A0 : KIND == G4_A1 ? G4_OFF_A1 : KIND == G4_B0 ? G4_OFF_B0 : G4_OFF_B1;
 }
 
-template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(const Gemm4Params p) {
+// SK = the split-K form (its own instantiation: the plain kernel sits at 249-250 VGPRs and must not pay for the K-range
+// bookkeeping or the partial-sum epilogue)
+template <bool NT, bool HF, bool SK = false> __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(const Gemm4Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w >> 2, wc = w & 3;
   const int r16 = lane & 15, g = lane >> 4;
   const int tiles_n = (p.N + G4_BN - 1) / G4_BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int splits = SK ? p.splits : 1;
+  const int ntiles = (int)gridDim.x / splits;
+  const int split = splits > 1 ? (int)blockIdx.x / ntiles : 0;
+  const int lid = splits > 1 ? (int)blockIdx.x % ntiles : xcd_remap(blockIdx.x, gridDim.x);
   const int64_t m0 = (int64_t)(lid / tiles_n) * G4_BM;
   const int n0 = (lid % tiles_n) * G4_BN;
   const int K = p.K, N = p.N;
   const int64_t M = p.M;
   const int nfull = K / G4_BK;
   const bool has_ext = HF || p.A2 != nullptr;
-  const int NTL = nfull + ((K % G4_BK) ? 1 : 0) + (has_ext ? 1 : 0);   // K-tiles
-  const int H = 4 * NTL;                                            // half-tiles
+  const int NTL_all = nfull + ((K % G4_BK) ? 1 : 0) + (has_ext ? 1 : 0);   // K-tiles of the product
+  // this block's K-tiles [kt0, NTL): the whole product, or its split's range (never empty: the launcher sizes kt_per so)
+  const int kt0 = splits > 1 ? split * p.kt_per : 0;
+  const int NTL = splits > 1 ? (kt0 + p.kt_per < NTL_all ? kt0 + p.kt_per : NTL_all) : NTL_all;
+  const int H = 4 * NTL;                                            // half-tiles (global numbering)
   const char* zp = zero_page_for(lane);
 
   // ------------------------------------------------------------------ DMA geometry (per lane)
@@ -172,6 +190,12 @@ template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gem
       else pB[hh][ii] = p.B + (int64_t)(m_kr0 + 4 * ii) * p.ldb + b_col_nn(hh);
     }
   const int64_t stepB = NT ? (int64_t)G4_BK : (int64_t)G4_BK * p.ldb;
+  if (kt0 > 0) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) pA[hh][ii] += (int64_t)kt0 * G4_BK, pB[hh][ii] += (int64_t)kt0 * stepB;
+  }
 
   // DMA of half-tile KIND of K-tile `tile`
   auto issue = [&](auto kind_c, int tile) {
@@ -193,7 +217,7 @@ template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gem
       return;
     }
     // checked path: the K tail of the main operands, or the extension tile
-    const bool ext = has_ext && tile == NTL - 1;
+    const bool ext = has_ext && tile == NTL_all - 1;
     const int k0 = ext ? 0 : nfull * G4_BK;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
@@ -467,16 +491,17 @@ template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gem
   using P2 = std::integral_constant<int, 2>;
   using P3 = std::integral_constant<int, 3>;
 
-  // ------------------------------------------------------------------ prologue: half-tiles 0 .. 5
-  issue(KA0{}, 0), issue(KB0{}, 0), issue(KB1{}, 0), issue(KA1{}, 0);
-  if (NTL > 1) issue(KA0{}, 1), issue(KB0{}, 1);
-  wait_groups<2>(NTL > 1 ? 4 : 2);     // A0, B0 of K-tile 0 have landed (this wave's pieces)
+  // ------------------------------------------------------------------ prologue: half-tiles 0 .. 5 (of this block's K range)
+  if (kt0 & 1) a_off[0] ^= G4_BUF, a_off[1] ^= G4_BUF, b_off[0] ^= G4_BUF, b_off[1] ^= G4_BUF;
+  issue(KA0{}, kt0), issue(KB0{}, kt0), issue(KB1{}, kt0), issue(KA1{}, kt0);
+  if (NTL - kt0 > 1) issue(KA0{}, kt0 + 1), issue(KB0{}, kt0 + 1);
+  wait_groups<2>(NTL - kt0 > 1 ? 4 : 2);     // A0, B0 of the first K-tile have landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();        // ... everyone's
   __builtin_amdgcn_sched_barrier(0);
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave row runs one barrier behind the first
   __builtin_amdgcn_sched_barrier(0);
 
-  int tile = 0;
+  int tile = kt0;
 #pragma unroll 1
   for (; tile < NTL - 2; ++tile) {
     phase(P0{}, T0{}, tile);
@@ -532,6 +557,77 @@ template <bool NT, bool HF> __global__ __launch_bounds__(G4_THREADS, 2) void gem
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // catch up: every wave has passed its last fragment read
   __builtin_amdgcn_sched_barrier(0);
+
+  // ------------------------------------------------------------------ split-K: partials out, or partners' partials in
+  // Every access to the partials and the flags carries sc1 (agent-scope coherence on gfx942 / gfx950: written through to,
+  // and read from, the level the eight XCD L2s share), the way the compiler emits agent-scope atomics; with that no
+  // buffer_wbl2 / buffer_inv is needed -- a release fence here writes back the whole L2 of the XCD once per workgroup
+  // (measured at 1024 x 4096 x 4096: 88 us per launch with __hip_atomic_store(release) / fence(acquire) in 192 workgroups, 58 us with
+  // sc1 accesses and register loads, 8 per thread in flight).
+  if constexpr (SK) {
+    float* part = p.partials + (size_t)lid * (size_t)(splits - 1) * (G4_BM * G4_BN);
+    int* flags = p.flags + lid * (splits - 1);
+    if (split < splits - 1) {
+      const f32x4* dst = (const f32x4*)(part + (size_t)split * (G4_BM * G4_BN)) + t;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+              asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (((mh * 4 + mt) * 2 + nh) * 2 + nt) * G4_THREADS),
+                           "v"(acc[mh][mt][nh][nt])
+                           : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has reached the coherence level
+      __syncthreads();                                   // ... every wave's
+      if (t == 0) {
+        const int one = 1;
+        asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(flags + split), "v"(one) : "memory");
+      }
+      return;
+    }
+    if (t == 0) {
+      // the partners have lower block ids (dispatched first) and never wait: these loops end; the bound only keeps a logic
+      // error from hanging the GPU (the result is then wrong, which the tests see)
+      for (int s = 0; s < splits - 1; ++s) {
+        int spins = 0, f = 0;
+        do {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + s) : "memory");
+          if (f == 0) __builtin_amdgcn_s_sleep(16);
+        } while (f == 0 && ++spins < (1 << 22));
+      }
+    }
+    __syncthreads();
+    // One workgroup pulls (S - 1) x 256 KiB: 8 loads per thread in flight (64 KiB per CU), partner after partner, quad after
+    // quad -- the sum order is fixed.  (Tried: the same through the idle ring by LDS-DMA, two 64-KiB rounds in flight -- the
+    // register allocator then spills inside the main loop, 58 -> 80 us at 1024 x 4096 x 4096; not kept.)
+    for (int s = 0; s < splits - 1; ++s) {
+      const f32x4* src = (const f32x4*)(part + (size_t)s * (G4_BM * G4_BN)) + t;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+          f32x4 tmp[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tmp[q]) : "v"(src + (mh * 16 + mp * 8 + q) * G4_THREADS) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(tmp[0]), "+v"(tmp[1]), "+v"(tmp[2]), "+v"(tmp[3]), "+v"(tmp[4]), "+v"(tmp[5]), "+v"(tmp[6]), "+v"(tmp[7])
+                       :
+                       : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) acc[mh][mp * 2 + m2][nh][nt] += tmp[(m2 * 2 + nh) * 2 + nt];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
 
   // ------------------------------------------------------------------ epilogue
   // acc[mh][mt][nh][nt][j] = C[row = 128 wr + 64 mh + 16 mt + r16][col = 64 wc + 32 nh + 16 nt + 4 g + j]
@@ -613,9 +709,39 @@ bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
   return true;
 }
 
+// split-K plan for an M x N x K product with an optional K-extension tile: splits (1 = none) and K-tiles per split.  Taken
+// when the output has at most 128 tiles (half of the CUs idle otherwise) and K >= 6144: the partial sums cost ~36 us per
+// launch whatever K is (48 MB written through by 192 workgroups, then 768 KiB pulled by each of the 64 last splits), so at
+// 1024 x 4096 x 4096 the split runs 58 us against 53 us for gemm3s's 256 small tiles, at K = 11008 95 us against 121 us
+// (profiles/r03_gemm_splitk.txt).  Up to four splits.
+static int gemm4_split_plan(int64_t M, int N, int K, bool has_ext, int* kt_per) {
+  const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
+  const int ntl = ceil_div(K, G4_BK) + (has_ext ? 1 : 0);
+  *kt_per = ntl;
+  if (tiles <= 0 || tiles > 128 || ntl < 96 || sw_on(SW_NO_SPLITK)) return 1;
+  int s = (int)(256 / tiles);
+  if (s > 4) s = 4;
+  while (s > 1 && ntl / s < 8) --s;
+  if (s <= 1) return 1;
+  *kt_per = ceil_div(ntl, s);
+  return ceil_div(ntl, *kt_per);
+}
+size_t gemm4_splitk_bytes(int64_t M, int N, int K, bool has_ext) {
+  int kt_per;
+  const int s = gemm4_split_plan(M, N, K, has_ext, &kt_per);
+  if (s <= 1) return 0;
+  const size_t tiles = (size_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
+  return tiles * (size_t)(s - 1) * (G4_BM * G4_BN * sizeof(float)) + 4096 + 256;
+}
+int gemm4_splits(int64_t M, int N, int K, bool has_ext, const void* ws, size_t ws_bytes) {
+  int kt_per;
+  const int s = gemm4_split_plan(M, N, K, has_ext, &kt_per);
+  return (s > 1 && ws && ws_bytes >= gemm4_splitk_bytes(M, N, K, has_ext)) ? s : 1;
+}
+
 int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
-                 float alpha, float beta, hipStream_t stream) {
+                 float alpha, float beta, hipStream_t stream, void* ws, size_t ws_bytes) {
   Gemm4Params p;
   p.A = (const bf16_t*)A, p.B = (const bf16_t*)B, p.A2 = (const bf16_t*)A2, p.B2 = (const bf16_t*)B2;
   p.C = (bf16_t*)C, p.bias = (const bf16_t*)bias;
@@ -625,15 +751,32 @@ int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   p.alpha = alpha, p.beta = beta;
   p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
   p.F = nullptr, p.ldf = 0, p.Hout = nullptr, p.r = 0, p.hscale = 0.f;
+  p.splits = 1, p.kt_per = 0, p.partials = nullptr, p.flags = nullptr;
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
-  if (nt) {
+  int64_t grid = tiles;
+  if (gemm4_splits(M, N, K, A2 != nullptr, ws, ws_bytes) > 1) {
+    p.splits = gemm4_split_plan(M, N, K, A2 != nullptr, &p.kt_per);
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    p.flags = (int*)base;                       // tiles * (splits - 1) ints (<= 384)
+    p.partials = (float*)(base + 4096);
+    const hipError_t e = hipMemsetAsync(p.flags, 0, (size_t)tiles * (p.splits - 1) * sizeof(int), stream);
+    if (e != hipSuccess) return (int)e;
+    grid = tiles * p.splits;
+  }
+  if (p.splits > 1 && nt) {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<true, false, true>);
+    hipLaunchKernelGGL((gemm4_kernel<true, false, true>), dim3((unsigned)grid), dim3(G4_THREADS), G4_LDS, stream, p);
+  } else if (p.splits > 1) {
+    SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<false, false, true>);
+    hipLaunchKernelGGL((gemm4_kernel<false, false, true>), dim3((unsigned)grid), dim3(G4_THREADS), G4_LDS, stream, p);
+  } else if (nt) {
     SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<true, false>);
-    hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+    hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3((unsigned)grid), dim3(G4_THREADS), G4_LDS, stream, p);
   } else {
     SOW_SET_MAX_LDS_ONCE(G4_LDS, gemm4_kernel<false, false>);
-    hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3((unsigned)tiles), dim3(G4_THREADS), G4_LDS, stream, p);
+    hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3((unsigned)grid), dim3(G4_THREADS), G4_LDS, stream, p);
   }
   SOW_CHECK_LAUNCH();
   return SOW_OK;
@@ -674,6 +817,7 @@ int launch_gemm4h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool n
   p.alpha = 1.f, p.beta = 0.f;
   p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
   p.F = (const bf16_t*)F, p.ldf = ldf, p.Hout = (bf16_t*)H, p.r = r, p.hscale = hscale;
+  p.splits = 1, p.kt_per = 0, p.partials = nullptr, p.flags = nullptr;
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;

@@ -147,9 +147,10 @@ int launch_gemm_x3(const void* A, int64_t lda, bool transA, const void* B, int64
 bool gemm2_supported(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                      const void* B2, int64_t ldb2, const void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
                      int dtype);
+// ws / ws_bytes: optional scratch for split-K (gemm4_splitk_bytes; short M), nullptr = never split
 int launch_gemm2(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
-                 float alpha, float beta, hipStream_t stream);
+                 float alpha, float beta, hipStream_t stream, void* ws = nullptr, size_t ws_bytes = 0);
 int launch_pad64(const void* in, void* out, int rows, int r, hipStream_t stream);
 // gemm3.hip (same contract as launch_gemm2; one wave per SIMD, 128x128 per wave, hand-interleaved k-loop: long K)
 int launch_gemm3(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
@@ -161,7 +162,11 @@ bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
                      int dtype);
 int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt, const void* A2, int64_t lda2,
                  const void* B2, int64_t ldb2, int k2, void* C, int64_t ldc, const void* bias, int64_t M, int N, int K,
-                 float alpha, float beta, hipStream_t stream);
+                 float alpha, float beta, hipStream_t stream, void* ws = nullptr, size_t ws_bytes = 0);
+// split-K of gemm4 for short M (<= 128 output tiles): scratch bytes (0 = the shape does not split), and the split count a
+// launch with this scratch takes (1 = none)
+size_t gemm4_splitk_bytes(int64_t M, int N, int K, bool has_ext);
+int gemm4_splits(int64_t M, int N, int K, bool has_ext, const void* ws, size_t ws_bytes);
 // gemm4.hip, gemm4h form: the projection H = hscale * X . op(F) computed by the kernel (a streaming pass over the row panel
 // ahead of the main loop) and used as the extension's A operand; F / G zero-padded to 64 columns where they are k-major
 bool gemm4h_supported(const void* X, int64_t ldx, const void* W, int64_t ldw, bool nt, const void* F, int64_t ldf,

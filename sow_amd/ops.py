@@ -71,6 +71,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 _WS_BYTES: dict = {}
+_GEMM_WS_BYTES: dict = {}
 _FWD_WS_BYTES: dict = {}
 
 
@@ -409,8 +410,15 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         if beta == 0.0:
             out.zero_()
         return out
-    _launch(dev, "sow_gemm", lib.sow_gemm, _ptr(A), max(A.stride(0), 1), int(trans_a), _ptr(B), max(B.stride(0), 1), int(trans_b),
-            _ptr(out), max(out.stride(0), 1), _ptr(bias), M, N, K, float(alpha), float(beta), dt)
+    # short bf16 products split K over workgroups and need scratch for the partial sums (0 for every other shape)
+    key = (M, N, K, bool(trans_a), dt)
+    nws = _GEMM_WS_BYTES.get(key)
+    if nws is None:
+        nws = _GEMM_WS_BYTES[key] = int(lib.sow_gemm_workspace_bytes(M, N, K, int(trans_a), dt))
+    ws = _ws(nws, dev) if nws else None
+    _launch(dev, "sow_gemm_ex", lib.sow_gemm_ex, _ptr(A), max(A.stride(0), 1), int(trans_a), _ptr(B), max(B.stride(0), 1),
+            int(trans_b), _ptr(out), max(out.stride(0), 1), _ptr(bias), M, N, K, float(alpha), float(beta), dt, _ptr(ws),
+            0 if ws is None else ws.numel())
     return out
 
 

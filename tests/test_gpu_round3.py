@@ -427,3 +427,58 @@ def test_chain3f_fp32_vs_oracle(case):
             continue
         assert rel_err(got.cpu(), ref) < tol, name
         assert rel_err(prev.cpu(), ref) < tol, name + " (chain2f)"
+
+
+# ---------------------------------------------------------------------------------------------
+# gemm4 split-K: short bf16 products (config 5: T = 1024) -- fewer output tiles than CUs, K split over workgroups
+@pytest.mark.parametrize("shape", [(1024, 11008, 4096), (1000, 6152, 4104), (512, 8192, 8192), (2048, 6144, 4096), (256, 16384, 512)])
+@pytest.mark.parametrize("trans_b", [False, True])
+def test_gemm_split_k(shape, trans_b):
+    """sow_gemm_ex with scratch: fp32 partial sums of the K ranges through the workspace, summed by the last split in a fixed
+    order -- against an fp32 product of the same bf16 operands, against the unsplit kernels (NO_SPLITK), with beta / bias,
+    and twice (bit-identical: the sum order does not depend on arrival order)."""
+    from sow_amd import _lib, ops
+    M, K, N = shape
+    gen = torch.Generator(device=DEV).manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=gen, device=DEV).bfloat16()
+    b = (torch.randn((N, K) if trans_b else (K, N), generator=gen, device=DEV) * 0.05).bfloat16()
+    bias = (torch.randn(N, generator=gen, device=DEV) * 0.1).bfloat16()
+    c0 = torch.randn(M, N, generator=gen, device=DEV).bfloat16()
+    lib = _lib.load()
+    assert lib.sow_gemm_workspace_bytes(M, N, K, 0, _lib.BF16) > 0, "shape expected to split"
+    ref = a.float() @ (b.float().t() if trans_b else b.float())
+    out = ops.gemm(a, b, trans_b=trans_b)
+    out2 = ops.gemm(a, b, trans_b=trans_b)
+    assert torch.equal(out, out2)
+    assert rel_err(out.float().cpu(), ref.cpu()) < 1e-2
+    with _lib.switch(NO_SPLITK=1):
+        assert lib.sow_gemm_workspace_bytes(M, N, K, 0, _lib.BF16) == 0
+        plain = ops.gemm(a, b, trans_b=trans_b)
+    assert rel_err(out.float().cpu(), plain.float().cpu()) < 8e-3   # one bf16 rounding of differently ordered fp32 sums
+    full = ops.gemm(a, b, trans_b=trans_b, out=c0.clone(), alpha=0.5, beta=0.25, bias=bias)
+    ref2 = 0.5 * ref + 0.25 * c0.float() + bias.float()
+    assert rel_err(full.float().cpu(), ref2.cpu()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(1024, 4096, 4096), (1024, 11008, 4096), (1024, 4096, 11008)])
+def test_dense_layer_short_t_split_k_vs_oracle(shape):
+    """The dense-accumulator layer at the config-5 shapes (llama-7b q / down / up, T = 4 x 256, r = 8, bf16): forward and
+    backward through sow_forward / sow_backward (split-K scratch inside the layer workspace) against the oracle."""
+    from sow_amd import ops
+    T, d_in, d_out = shape
+    r = 8
+    gen = torch.Generator(device=DEV).manual_seed(d_in + d_out)
+    x = torch.randn(T, d_in, generator=gen, device=DEV).bfloat16()
+    dy = torch.randn(T, d_out, generator=gen, device=DEV).bfloat16()
+    A = (torch.randn(d_in, r, generator=gen, device=DEV) * 0.05).bfloat16()
+    B = (torch.randn(r, d_out, generator=gen, device=DEV) * 0.05).bfloat16()
+    W = (torch.randn(d_in, d_out, generator=gen, device=DEV) * 0.02).bfloat16()
+    y, h = ops.sow_forward(x, A, B, W, None, None, 0.125)
+    dx, dA, dB, _ = ops.sow_backward(dy, x, h, A, B, W, None, 0.125, False)
+    f = lambda t: t.float().cpu()
+    y_ref = O.sow_forward(f(x), [f(A)], [f(B)], f(W), None, 0.125, None)
+    dx_ref, dA_ref, dB_ref, _ = O.sow_backward(f(dy), f(x), [f(A)], [f(B)], f(W), None, 0.125, False)
+    assert rel_err(f(y), y_ref) < 2e-2
+    assert rel_err(f(dx), dx_ref) < 2e-2
+    assert rel_err(f(dA), dA_ref[0]) < 2e-2
+    assert rel_err(f(dB), dB_ref[0]) < 2e-2
