@@ -40,7 +40,9 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 MFMA_F32_TFLOPS = 157.0    # fp32 matrix peak
 # HBM bytes per launch of the roofline kernel, from the rocprofv3 PMC passes made at the commit named inside the file
 # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_traffic.py); absent or for another kernel -> null in the line.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+# the dense-accumulator layer as ONE launch per pass (N <= 512: 40 of the 56 layers): the section's roofline kernel
+DENSE_KERNEL = "sow::gemm4_kernel<false, true, false> = gemm4h (projection pass + K-extended bf16 product in one launch, N <= 512)"
 LLAMA_60M = dict(hidden=512, inter=1376, layers=8)
 BLOCK_NAMES = ["q", "k", "v", "o", "gate", "up", "down"]
 BLOCK_GROUPS = [[0, 1, 2], [3], [4, 5], [6]]   # model-independent layers inside one decoder block
@@ -572,7 +574,8 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
             if acc == "none" and dtype_name == "bf16" and not overlap:
                 res["per_launch"] = per_launch_table(stack, stream, T, args.rank, es)
             if acc == "dense":
-                # layers whose forward is exactly ONE gemm2h launch (N <= 512: 40 of the 56); flops of one launch =
+                # layers whose forward is exactly ONE launch (gemm4h: projection pass + K-extended product, N <= 512: 40 of the
+                # 56; gemm2h under the NO_GEMM4H switch); flops of one launch =
                 # dense product + rank-r projection and extension
                 one = [gi for gi, ids in enumerate(stack.group_layers) if all(shapes[i][1] <= 512 for i in ids)]
                 n_l = sum(len(stack.group_layers[gi]) for gi in one)
@@ -713,8 +716,8 @@ def main():
     if rank == 0:
         n_layers = len(shapes)
         if args.acc == "dense":
-            # steady state after the first accumulate(): MFMA-bound; dominant kernel by total time = gemm2h
-            kname = "sow::gemm2h_kernel<false> (dense-accumulator forward, projection fused)"
+            # steady state after the first accumulate(): MFMA-bound; dominant kernel by total time = the one-launch forward
+            kname = DENSE_KERNEL
             g2h = head["gemm2h"]
             roof = {"bound": "mfma", "kernel": kname, "achieved": g2h["tflops"], "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": g2h["tflops"] / MFMA_BF16_TFLOPS, "traffic": None, "avg_launch_ms": g2h["avg_launch_ms"],
@@ -722,7 +725,7 @@ def main():
         else:
             # dominant kernel (largest total time in profiles/): the forward chain kernel.  Algorithmic bytes per launch =
             # sum over the launch's layers of T*(d_in + d_out + r)*s (x read once, y written once, h saved once).
-            kernel_sym = "chain2_kernel<false, true>" if args.dtype == "bf16" else "chain2f_kernel<false>"   # <backward, bf16 park tiles>
+            kernel_sym = "chain2_kernel<false, true>" if args.dtype == "bf16" else "chain3f_kernel<2, 4>"   # <backward, bf16 park tiles>
             kname = f"sow::{kernel_sym} (fused forward chain{', fp32' if args.dtype != 'bf16' else ''})"
             nl = head["n_fwd_launches"]
             kbytes = sum(T * (di + do + args.rank) * es for di, do in shapes) / nl
@@ -779,7 +782,7 @@ def main():
             "fwd_ms": d["fwd_ms"], "bwd_ms": d["bwd_ms"], "tokens_per_s": T / (dms * 1e-3),
             "tflops": d["flops"] / (dms * 1e-3) / 1e12,
             "frac_of_bf16_mfma_peak": d["flops"] / (dms * 1e-3) / 1e12 / MFMA_BF16_TFLOPS,
-            "roofline": {"bound": "mfma", "kernel": "sow::gemm2h_kernel<false> (one launch per forward pass, N <= 512)",
+            "roofline": {"bound": "mfma", "kernel": DENSE_KERNEL,
                          "achieved": g2h["tflops"], "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": g2h["tflops"] / MFMA_BF16_TFLOPS, "traffic": None, "avg_launch_ms": g2h["avg_launch_ms"],
                          "launches_timed": g2h["launches"]}}
