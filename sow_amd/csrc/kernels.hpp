@@ -224,11 +224,12 @@ struct AccItem {
   int d_in, d_out, r, r_new, kc;
   float scale, beta;
 };
-constexpr int ACC_MAXB = 48;   // layers per launch (kernel-argument block of 48 x 80 bytes)
+constexpr int ACC_MAXB = 40;   // layers per launch: the by-value argument block is 40 x 96 bytes + 8 = 3848 bytes, under HIP's 4-KiB limit
 struct AccBatch {
   AccItem it[ACC_MAXB];
   int n;
 };
+static_assert(sizeof(AccBatch) <= 4096, "by-value kernel arguments must stay under 4 KiB");
 int launch_accumulate_batch(const AccItem* items, int n, int dtype, hipStream_t stream);
 // misc.hip
 int launch_multi_zero(void* const* ptrs, const int64_t* bytes, int n, hipStream_t stream);

@@ -140,8 +140,10 @@ def accumulate(model):
 
     The layers are independent and each one's re-factorisation is a single-workgroup Householder panel (latency
     bound, ~0.5 ms), so on the GPU they are spread round-robin over a few side streams that fork from and join the
-    current stream: 56 layers take ~7 QR latencies instead of 56.  Host order is unchanged, so the Gaussian
-    re-initialisation draws come out of the generator exactly as in the sequential loop."""
+    current stream: 56 layers take ~7 QR latencies instead of 56.  The batched path (layers on the dense-accumulator
+    branch) consumes the generator DIFFERENTLY from the sequential loop: it draws only the [in, rank] columns that reach
+    Q[:, :rank], for all its layers in one normal_() per (device, dtype), where the per-layer path (and the reference,
+    sow.py:163-165) draws [in, out] per layer -- so a seeded run is reproducible within a path, not across the two."""
     mods = [m for _, m in model.named_modules() if isinstance(m, SoWLinear)]
     # layers attached to a FactorBucket (sow_amd/dp.py): pending partial sums belong to the OLD factors -- reduce them
     # first; afterwards the rebound .data tensors are copied back into the flat buffer so the fused optimizer and the
@@ -189,11 +191,13 @@ def _accumulate_batched(mods):
 
     from . import _lib
     lib = _lib.load()
-    dev = mods[0].downscale_weights._parameters["0"].device
-    by_dtype = {}
+    # one C call per (device, dtype): a launch takes raw pointers of ONE device (a model spread over several GPUs gets one
+    # call, with its own draws and workspace, per GPU)
+    by_key = {}
     for m in mods:
-        by_dtype.setdefault(m.downscale_weights._parameters["0"].dtype, []).append(m)
-    for dtype, group in by_dtype.items():
+        A0 = m.downscale_weights._parameters["0"]
+        by_key.setdefault((A0.device, A0.dtype), []).append(m)
+    for (dev, dtype), group in by_key.items():
         es = 2 if dtype == torch.bfloat16 else 4
         hooked = [("_fresh_gaussian" in m.__dict__) or (type(m)._fresh_gaussian is not SoWLinear._fresh_gaussian_default)
                   for m in group]
