@@ -591,8 +591,9 @@ def measure_stack(args, dtype_name, acc, world, rank, device, steps, warmup, det
 
 def northstar(device, reps=20, warm=5):
     """BASELINE.json north_star point: ONE SoWLinear forward + backward at r = 50, d_in = d_out = 768, T = 32768, in bf16 and
-    in fp32, through the single-layer C-ABI calls (sow_forward, sow_backward), 4 rotating buffer sets in one HIP graph so that
-    no replay finds its inputs in the Infinity Cache; per-replay HIP events.  Flops = 6*T*r*(d_in+d_out) (SURVEY 8d);
+    in fp32, through the C-ABI layer calls (sow_forward_group / sow_backward_group with n = 1: the same kernels as sow_forward /
+    sow_backward), 4 rotating buffer sets -- inputs AND outputs -- in one HIP graph so that no replay finds its inputs in the
+    Infinity Cache or has its outputs absorbed by it; per-replay HIP events.  Flops = 6*T*r*(d_in+d_out) (SURVEY 8d);
     algorithmic bytes = T*(3 d_in + 2 d_out + 2 r)*s.  `frac` = TFLOP/s over the MFMA peak of the tensors' dtype (2.5 PF bf16,
     157 TF fp32); `frac_of_roofline` = over min(that peak, AI x 8 TB/s)."""
     from sow_amd import _lib, ops
@@ -606,10 +607,17 @@ def northstar(device, reps=20, warm=5):
         A = torch.linalg.qr(torch.randn(d, r, generator=g, device=device).cpu() * 0.02)[0].to(device).to(dtype).contiguous()
         B = (torch.randn(r, d, device=device, generator=g) * 0.02).to(dtype)
 
+        # every buffer set has its OWN outputs (y, dX, h, workspace), as every layer of the headline stack has: through
+        # ops.sow_forward / sow_backward they would come out of the caching allocator -- the same blocks for every set -- and
+        # their writes would be absorbed by the 256-MiB Infinity Cache (~3 us of 180 at the fp32 point)
+        dA, dB = torch.empty_like(A), torch.empty_like(B)
+        grps = [ops.LayerGroup([ops.LayerCall(xs[i], A, B, dy2=dys[i], dx=torch.empty_like(xs[i]), out=(dA, dB, None))])
+                for i in range(nset)]
+
         def step():
-            for i in range(nset):
-                _, h = ops.sow_forward(xs[i], A, B, None, None, None, 1.0)
-                ops.sow_backward(dys[i], xs[i], h, A, B, None, None, 1.0, False)
+            for grp in grps:
+                grp.forward()
+                grp.backward()
 
         s = torch.cuda.Stream(device=device)
         with torch.cuda.stream(s):
@@ -642,7 +650,7 @@ def northstar(device, reps=20, warm=5):
             rec["form"] = "exact (v_mfma_f32_32x32x2_f32)" if exact else "3xbf16 (fp32 operands split into three bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-equivalent results, runs on the bf16 matrix pipe)"
             rec["peak_note"] = "frac divides by the 157 TF fp32 matrix peak, the figure BASELINE.json's target is stated against"
         out[name] = rec
-        del xs, dys
+        del xs, dys, grps
     torch.cuda.empty_cache()
     return out
 
