@@ -29,7 +29,7 @@
 //     64-bit add; rows / columns beyond the matrix are CLAMPED (they only feed outputs that are never stored); the K tail
 //     and the extension tile take a checked path that reads the zero page where k is out of range;
 //   * short M (config 5: T = 1024 -> 64 tiles for a 4096-wide output) runs split-K: S blocks per tile, each on a K range,
-//     fp32 partials through the caller's workspace, the last split sums them in a fixed order (see Gemm4Params).
+//     fp32 partial products through the caller's workspace, summed in split order by a second, chip-wide launch.
 #include "kernels.hpp"
 #include "lds_dma.hpp"
 #include <type_traits>
@@ -69,13 +69,10 @@ struct Gemm4Params {
   int r;
   float hscale;
   // split-K (short M: fewer output tiles than CUs).  splits > 1: block b = split * tiles + tile runs K-tiles
-  // [split * kt_per, ...) of its tile; splits 0 .. S-2 leave their fp32 accumulators in `partials` ([tile][split][32][512]
-  // float4: register quad q of thread t) and raise flags[tile * (S - 1) + split]; the LAST split -- the highest block ids,
-  // dispatched after its partners -- waits for them, adds the partials in split order (deterministic) and runs the epilogue.
-  // flags are zeroed by the launcher (hipMemsetAsync ahead of the kernel).
+  // [split * kt_per, ...) of its tile and leaves the fp32 sum of that range in partials[split][M][N]; a second launch
+  // (gemm4_splitk_reduce_kernel, every CU) adds the splits in order and applies alpha / beta / bias.
   int splits, kt_per;
   float* partials;
-  int* flags;
 };
 
 __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
@@ -558,77 +555,6 @@ template <bool NT, bool HF, bool SK = false> __global__ __launch_bounds__(G4_THR
   if (wr == 0) __builtin_amdgcn_s_barrier();   // catch up: every wave has passed its last fragment read
   __builtin_amdgcn_sched_barrier(0);
 
-  // ------------------------------------------------------------------ split-K: partials out, or partners' partials in
-  // Every access to the partials and the flags carries sc1 (agent-scope coherence on gfx942 / gfx950: written through to,
-  // and read from, the level the eight XCD L2s share), the way the compiler emits agent-scope atomics; with that no
-  // buffer_wbl2 / buffer_inv is needed -- a release fence here writes back the whole L2 of the XCD once per workgroup
-  // (measured at 1024 x 4096 x 4096: 88 us per launch with __hip_atomic_store(release) / fence(acquire) in 192 workgroups, 58 us with
-  // sc1 accesses and register loads, 8 per thread in flight).
-  if constexpr (SK) {
-    float* part = p.partials + (size_t)lid * (size_t)(splits - 1) * (G4_BM * G4_BN);
-    int* flags = p.flags + lid * (splits - 1);
-    if (split < splits - 1) {
-      const f32x4* dst = (const f32x4*)(part + (size_t)split * (G4_BM * G4_BN)) + t;
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (((mh * 4 + mt) * 2 + nh) * 2 + nt) * G4_THREADS),
-                           "v"(acc[mh][mt][nh][nt])
-                           : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has reached the coherence level
-      __syncthreads();                                   // ... every wave's
-      if (t == 0) {
-        const int one = 1;
-        asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(flags + split), "v"(one) : "memory");
-      }
-      return;
-    }
-    if (t == 0) {
-      // the partners have lower block ids (dispatched first) and never wait: these loops end; the bound only keeps a logic
-      // error from hanging the GPU (the result is then wrong, which the tests see)
-      for (int s = 0; s < splits - 1; ++s) {
-        int spins = 0, f = 0;
-        do {
-          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + s) : "memory");
-          if (f == 0) __builtin_amdgcn_s_sleep(16);
-        } while (f == 0 && ++spins < (1 << 22));
-      }
-    }
-    __syncthreads();
-    // One workgroup pulls (S - 1) x 256 KiB: 8 loads per thread in flight (64 KiB per CU), partner after partner, quad after
-    // quad -- the sum order is fixed.  (Tried: the same through the idle ring by LDS-DMA, two 64-KiB rounds in flight -- the
-    // register allocator then spills inside the main loop, 58 -> 80 us at 1024 x 4096 x 4096; not kept.)
-    for (int s = 0; s < splits - 1; ++s) {
-      const f32x4* src = (const f32x4*)(part + (size_t)s * (G4_BM * G4_BN)) + t;
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
-          f32x4 tmp[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(tmp[q]) : "v"(src + (mh * 16 + mp * 8 + q) * G4_THREADS) : "memory");
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(tmp[0]), "+v"(tmp[1]), "+v"(tmp[2]), "+v"(tmp[3]), "+v"(tmp[4]), "+v"(tmp[5]), "+v"(tmp[6]), "+v"(tmp[7])
-                       :
-                       : "memory");
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-              for (int nt = 0; nt < 2; ++nt) acc[mh][mp * 2 + m2][nh][nt] += tmp[(m2 * 2 + nh) * 2 + nt];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-  }
-
   // ------------------------------------------------------------------ epilogue
   // acc[mh][mt][nh][nt][j] = C[row = 128 wr + 64 mh + 16 mt + r16][col = 64 wc + 32 nh + 16 nt + 4 g + j]
   float* sc = (float*)(smem + w * G4_SCR);
@@ -650,6 +576,13 @@ template <bool NT, bool HF, bool SK = false> __global__ __launch_bounds__(G4_THR
         if (grow < M && gcol < N) {
           float v[8];
           const f32x4 t0 = *(const f32x4*)(sc + r * G4_SCR_LD + c), t1 = *(const f32x4*)(sc + r * G4_SCR_LD + c + 4);
+          if constexpr (SK) {
+            // split-K: the fp32 sum of this block's K range, row-major [split][M][N] (256-byte row segments); alpha, beta, bias and
+            // the rounding to bf16 happen once, in gemm4_splitk_reduce_kernel
+            float* pd = p.partials + ((size_t)split * (size_t)M + (size_t)grow) * (size_t)N + gcol;
+            *(f32x4*)pd = t0, *(f32x4*)(pd + 4) = t1;
+            continue;
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = t0[j] * p.alpha, v[4 + j] = t1[j] * p.alpha;
           bf16_t* dst = p.C + grow * p.ldc + gcol;
@@ -709,11 +642,45 @@ bool gemm4_supported(const void* A, int64_t lda, const void* B, int64_t ldb, boo
   return true;
 }
 
+// C = alpha * sum_s partial[s] + beta * C + bias, 8 columns per thread (N % 8 == 0), splits added in order (deterministic)
+__global__ __launch_bounds__(256) void gemm4_splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t M, int N,
+                                                                  bf16_t* C, int64_t ldc, const bf16_t* bias, float alpha, float beta) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n8 = N / 8;
+  if (idx >= M * n8) return;
+  const int64_t row = idx / n8;
+  const int col = (int)(idx % n8) * 8;
+  const float* src = part + row * N + col;
+  f32x4 a0 = __builtin_nontemporal_load((const f32x4*)src), a1 = __builtin_nontemporal_load((const f32x4*)(src + 4));
+  for (int s = 1; s < splits; ++s) {
+    const float* q = src + (size_t)s * (size_t)M * (size_t)N;
+    a0 += __builtin_nontemporal_load((const f32x4*)q), a1 += __builtin_nontemporal_load((const f32x4*)(q + 4));
+  }
+  float v[8] = {a0[0] * alpha, a0[1] * alpha, a0[2] * alpha, a0[3] * alpha, a1[0] * alpha, a1[1] * alpha, a1[2] * alpha, a1[3] * alpha};
+  bf16_t* dst = C + row * ldc + col;
+  if (beta != 0.f) {
+    const u32x4 old = *(const u32x4*)dst;
+    const bf16_t* o = (const bf16_t*)&old;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += beta * (float)o[j];
+  }
+  if (bias) {
+    const u32x4 bv = *(const u32x4*)(bias + col);
+    const bf16_t* b = (const bf16_t*)&bv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += (float)b[j];
+  }
+  u32x4 pk;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pk[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+  *(u32x4*)dst = pk;
+}
+
 // split-K plan for an M x N x K product with an optional K-extension tile: splits (1 = none) and K-tiles per split.  Taken
-// when the output has at most 128 tiles (half of the CUs idle otherwise) and K >= 6144: the partial sums cost ~36 us per
-// launch whatever K is (48 MB written through by 192 workgroups, then 768 KiB pulled by each of the 64 last splits), so at
-// 1024 x 4096 x 4096 the split runs 58 us against 53 us for gemm3s's 256 small tiles, at K = 11008 95 us against 121 us
-// (profiles/r03_gemm_splitk.txt).  Up to four splits.
+// when the output has at most 128 tiles (half of the CUs idle otherwise) and K >= 6144: the partial products cost a write and
+// a read of S x M x N fp32 whatever K is -- ~33 us at 1024 x 4096, S = 4 -- so at K = 4096 the split (56-58 us) only ties with
+// gemm3s's 256 small tiles (53-55 us) and is not worth its 64 MB of scratch; at K = 11008 it runs 90-93 us against 121-125
+// (profiles/r03_gemm_splitk.txt).  Up to four splits, at least 8 K-tiles each.
 static int gemm4_split_plan(int64_t M, int N, int K, bool has_ext, int* kt_per) {
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   const int ntl = ceil_div(K, G4_BK) + (has_ext ? 1 : 0);
@@ -730,8 +697,7 @@ size_t gemm4_splitk_bytes(int64_t M, int N, int K, bool has_ext) {
   int kt_per;
   const int s = gemm4_split_plan(M, N, K, has_ext, &kt_per);
   if (s <= 1) return 0;
-  const size_t tiles = (size_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
-  return tiles * (size_t)(s - 1) * (G4_BM * G4_BN * sizeof(float)) + 4096 + 256;
+  return (size_t)s * (size_t)M * (size_t)N * sizeof(float) + 256;
 }
 int gemm4_splits(int64_t M, int N, int K, bool has_ext, const void* ws, size_t ws_bytes) {
   int kt_per;
@@ -751,18 +717,14 @@ int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
   p.alpha = alpha, p.beta = beta;
   p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
   p.F = nullptr, p.ldf = 0, p.Hout = nullptr, p.r = 0, p.hscale = 0.f;
-  p.splits = 1, p.kt_per = 0, p.partials = nullptr, p.flags = nullptr;
+  p.splits = 1, p.kt_per = 0, p.partials = nullptr;
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;
   int64_t grid = tiles;
   if (gemm4_splits(M, N, K, A2 != nullptr, ws, ws_bytes) > 1) {
     p.splits = gemm4_split_plan(M, N, K, A2 != nullptr, &p.kt_per);
-    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    p.flags = (int*)base;                       // tiles * (splits - 1) ints (<= 384)
-    p.partials = (float*)(base + 4096);
-    const hipError_t e = hipMemsetAsync(p.flags, 0, (size_t)tiles * (p.splits - 1) * sizeof(int), stream);
-    if (e != hipSuccess) return (int)e;
+    p.partials = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     grid = tiles * p.splits;
   }
   if (p.splits > 1 && nt) {
@@ -779,6 +741,12 @@ int launch_gemm4(const void* A, int64_t lda, const void* B, int64_t ldb, bool nt
     hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3((unsigned)grid), dim3(G4_THREADS), G4_LDS, stream, p);
   }
   SOW_CHECK_LAUNCH();
+  if (p.splits > 1) {
+    const int64_t work = M * (N / 8);
+    hipLaunchKernelGGL(gemm4_splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p.partials, p.splits, M,
+                       N, p.C, p.ldc, p.bias, p.alpha, p.beta);
+    SOW_CHECK_LAUNCH();
+  }
   return SOW_OK;
 }
 
@@ -817,7 +785,7 @@ int launch_gemm4h(const void* X, int64_t ldx, const void* W, int64_t ldw, bool n
   p.alpha = 1.f, p.beta = 0.f;
   p.nt_store = SOW_GEMM_NT(M) ? 1 : 0;
   p.F = (const bf16_t*)F, p.ldf = ldf, p.Hout = (bf16_t*)H, p.r = r, p.hscale = hscale;
-  p.splits = 1, p.kt_per = 0, p.partials = nullptr, p.flags = nullptr;
+  p.splits = 1, p.kt_per = 0, p.partials = nullptr;
   const int64_t tiles = (int64_t)ceil_div(M, G4_BM) * ceil_div(N, G4_BN);
   if (tiles <= 0) return SOW_OK;
   if (tiles > 0x7fffffff) return SOW_ERR_SHAPE;

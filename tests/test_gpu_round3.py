@@ -434,9 +434,9 @@ def test_chain3f_fp32_vs_oracle(case):
 @pytest.mark.parametrize("shape", [(1024, 11008, 4096), (1000, 6152, 4104), (512, 8192, 8192), (2048, 6144, 4096), (256, 16384, 512)])
 @pytest.mark.parametrize("trans_b", [False, True])
 def test_gemm_split_k(shape, trans_b):
-    """sow_gemm_ex with scratch: fp32 partial sums of the K ranges through the workspace, summed by the last split in a fixed
-    order -- against an fp32 product of the same bf16 operands, against the unsplit kernels (NO_SPLITK), with beta / bias,
-    and twice (bit-identical: the sum order does not depend on arrival order)."""
+    """sow_gemm_ex with scratch: fp32 partial products of the K ranges through the workspace, summed in split order by a second
+    launch -- against an fp32 product of the same bf16 operands, against the unsplit kernels (NO_SPLITK), with beta / bias,
+    and twice (bit-identical)."""
     from sow_amd import _lib, ops
     M, K, N = shape
     gen = torch.Generator(device=DEV).manual_seed(M + K + N)
