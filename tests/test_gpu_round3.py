@@ -482,3 +482,35 @@ def test_dense_layer_short_t_split_k_vs_oracle(shape):
     assert rel_err(f(dx), dx_ref) < 2e-2
     assert rel_err(f(dA), dA_ref[0]) < 2e-2
     assert rel_err(f(dB), dB_ref[0]) < 2e-2
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_chain3f_and_quad_kernel_random_shapes(seed):
+    """Seeded random shapes for the long-T fp32 kernels (chain3f, the quad weight-gradient kernel where it applies): widths that
+    are multiples of 4 but of nothing else, every rank count, ragged token counts, optional bias -- against the oracle."""
+    import random
+    from sow_amd import ops
+    rnd = random.Random(1000 + seed)
+    T = rnd.choice([8192, 8192 + 4 * rnd.randint(1, 300), 16384 + rnd.randint(1, 127)])
+    d_in, d_out = 4 * rnd.randint(3, 160), 4 * rnd.randint(3, 160)
+    r = rnd.choice([1, 2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 63, 64])
+    has_bias = rnd.random() < 0.5
+    scale = rnd.choice([1.0, 0.5, 1.0 / r])
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(T, d_in, generator=gen, device=DEV)
+    dy = torch.randn(T, d_out, generator=gen, device=DEV)
+    A = torch.randn(d_in, r, generator=gen, device=DEV) * 0.05
+    B = torch.randn(r, d_out, generator=gen, device=DEV) * 0.05
+    bias = torch.randn(d_out, generator=gen, device=DEV) * 0.1 if has_bias else None
+    y, h = ops.sow_forward(x, A, B, None, None, bias, scale)
+    dx, dA, dB, db = ops.sow_backward(dy, x, h, A, B, None, None, scale, has_bias)
+    cpu = lambda t: None if t is None else t.cpu()
+    y_ref = O.sow_forward(x.cpu(), [A.cpu()], [B.cpu()], None, None, scale, cpu(bias))
+    dx_ref, dA_ref, dB_ref, db_ref = O.sow_backward(dy.cpu(), x.cpu(), [A.cpu()], [B.cpu()], None, None, scale, has_bias)
+    what = f"T={T} {d_in}->{d_out} r={r} bias={has_bias}"
+    assert rel_err(y.cpu(), y_ref) < 1e-5, what
+    assert rel_err(dx.cpu(), dx_ref) < 1e-5, what
+    assert rel_err(dA.cpu(), dA_ref[0]) < 2e-5, what
+    assert rel_err(dB.cpu(), dB_ref[0]) < 2e-5, what
+    if has_bias:
+        assert rel_err(db.cpu(), db_ref) < 2e-5, what
