@@ -147,22 +147,35 @@ template <int NT, int KS> __global__ __launch_bounds__(C4_THREADS, 2) void chain
   };
   // X DMA: a stage is 8 instructions of 4 token rows; this wave issues 4 hh .. 4 hh + 3 (rows 16 hh ..); 16-byte chunk c of
   // a row at c ^ (row & 15) (XOR on the per-lane SOURCE address)
-  const float* xsrc[4];
+  // (running per-lane source pointers; rows beyond M read the zero page with a zero step, so that a full stage -- every one but
+  // possibly the last -- is four DMA instructions and four pointer increments)
+  const char* xsrc[4];
   int xcol[4];
+  int64_t xstep[4];
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
     const int row = 4 * (4 * hh + ii) + (lane >> 4);
     const int lc = (lane & 15) ^ (row & 15);
     const int64_t tk = tok0 + row;
     xcol[ii] = 4 * lc;
-    xsrc[ii] = tk < p.M ? p.X + tk * p.ldx + 4 * lc : nullptr;
+    xsrc[ii] = tk < p.M ? (const char*)(p.X + tk * p.ldx + 4 * lc) : zp;
+    xstep[ii] = tk < p.M ? 256 : 0;
   }
-  auto issue_x = [&](int st) {
+  auto issue_x = [&](int st) {   // strictly in order of st
     char* dst = xring + (st % C4_XDEPTH) * C4_XSTAGE + (4 * hh) * 1024;
+    if (st * 64 + 64 <= D1) {   // wave-uniform
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const void* src = (xsrc[ii] && st * 64 + xcol[ii] < D1) ? (const void*)(xsrc[ii] + st * 64) : (const void*)zp;
-      dma16(src, dst + ii * 1024);
+      for (int ii = 0; ii < 4; ++ii) {
+        dma16(xsrc[ii], dst + ii * 1024);
+        xsrc[ii] += xstep[ii];
+      }
+    } else {                    // the K tail: columns beyond D1 read zeros
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const void* src = (st * 64 + xcol[ii] < D1) ? (const void*)xsrc[ii] : (const void*)zp;
+        dma16(src, dst + ii * 1024);
+        xsrc[ii] += xstep[ii];
+      }
     }
   };
 
