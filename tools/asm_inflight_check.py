@@ -6,6 +6,10 @@ read and the wait captures garbage (seen twice while writing chain3f.hip: a spli
 and register copies behind conditionally executed reads).  Linear scan per function: pending = destination registers of
 the LDS reads issued since the last wait; `s_waitcnt lgkmcnt(N)` keeps the N youngest; any instruction that names a
 pending register is reported.  Scalar-memory loads share the counter and only make a wait stricter, so they are ignored.
+The scan is LINEAR in listing order and knows nothing of control flow: code laid out behind a loop whose exit passes a wait
+(an epilogue after a `continue`, the far arm of a branch) can be reported although no path reaches it with the read in
+flight -- read the block structure around a report before believing it (chain2f.hip and gemm3s.hip list such reports and
+pass their parity tests); zero reports on straight-line kernels (chain3f, the quad kernel, gemm4) is the useful signal.
 usage: asm_inflight_check.py file.s [function-substring]"""
 import re, sys
 src = open(sys.argv[1]).read().splitlines()
