@@ -1253,7 +1253,12 @@ int tn_pick_slabs(int64_t T, int total_colgroups, int total_colgroup_pairs, int 
     // no rounding to a multiple of 8 (d = 768: 21 slabs / 252 blocks instead of 16 / 192)
     if (dtype == SOW_F32) ns = 256 / cg2;
     // fp32 quad kernel (skinny_tn_f32q.hip): four column groups per block, one 8-wave workgroup per CU, one round
-    if (dtype == SOW_F32 && total_colgroup_quads > 0) ns = 256 / total_colgroup_quads;
+    // (slab counts are padded to a multiple of 8 per operand there -- same-slab ranges share an XCD -- so a multiple of 8 it is,
+    // where that still leaves at least 8 slabs: the padded grid must stay within the one round)
+    if (dtype == SOW_F32 && total_colgroup_quads > 0) {
+      ns = 256 / total_colgroup_quads;
+      if (ns >= 8) ns &= ~7;
+    }
     if (ns > max_ns) ns = (int)max_ns;
     if (ns < 1) ns = 1;
   }

@@ -62,10 +62,16 @@ __global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cg = w & 3, th = w >> 2;
+  // Block -> (operand, range, slab), XCD-aware: block b runs on XCD b % 8 (round-robin dispatch), so the ranges of ONE slab are
+  // given consecutive places in the same XCD's sequence -- they read the same S rows, which then come from that XCD's L2 after
+  // the first read (PMC at the north-star point: 252 -> 218 MB read per launch = the algorithmic bytes; the launch time did not
+  // change -- the kernel is bound by its own instruction issue, not by that traffic).  Slab counts are padded to a multiple of 8 per
+  // operand; the surplus blocks leave at once.
   int b = blockIdx.x, jid = 0;
+  const int ns8 = (p.ns + 7) / 8 * 8;
   const int nr0 = (p.job[0].ncg + 3) / 4;
-  if (p.njobs > 1 && b >= nr0 * p.ns) {
-    b -= nr0 * p.ns;
+  if (p.njobs > 1 && b >= nr0 * ns8) {
+    b -= nr0 * ns8;
     jid = 1;
   }
   const float* Mg = (const float*)(jid ? p.job[1].M : p.job[0].M);
@@ -74,7 +80,9 @@ __global__ __launch_bounds__(64 * TNQ_WAVES, 2) void tn_partial_f32_quad_kernel(
   const int64_t ldm = jid ? p.job[1].ldm : p.job[0].ldm;
   const int D = jid ? p.job[1].D : p.job[0].D;
   const int ncg = jid ? p.job[1].ncg : p.job[0].ncg;
-  const int range = b / p.ns, slab = b % p.ns;
+  const int nrange = (ncg + 3) / 4;
+  const int range = (b >> 3) % nrange, slab = ((b >> 3) / nrange) * 8 + (b & 7);
+  if (slab >= p.ns) return;                  // padding block (uniform: before any barrier)
   const int g = range * 4 + cg;              // this wave's column group
   const bool active = g < ncg;
   const int d0 = g * TN_BD;
@@ -328,7 +336,7 @@ bool tn_f32q_ok(const TnParams& p) {
 
 int launch_tn_f32q(const TnParams& p, hipStream_t stream) {
   int blocks = 0;
-  for (int j = 0; j < p.njobs; ++j) blocks += (p.job[j].ncg + 3) / 4 * p.ns;
+  for (int j = 0; j < p.njobs; ++j) blocks += (p.job[j].ncg + 3) / 4 * ((p.ns + 7) / 8 * 8);
   if (blocks <= 0) return SOW_OK;
   SOW_SET_MAX_LDS_ONCE(TNQ_LDS, tn_partial_f32_quad_kernel);
   hipLaunchKernelGGL(tn_partial_f32_quad_kernel, dim3(blocks), dim3(64 * TNQ_WAVES), TNQ_LDS, stream, p);
