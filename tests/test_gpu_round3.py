@@ -387,6 +387,7 @@ C3F_CASES = [
     (8192, 768, 768, 64, True, 1.0, None),         # r = 64: no free ones column (dbias by column sums)
     (8192, 128, 64, 2, False, 1.0, None),
     (8192, 256, 320, 16, True, 0.25, "lowrank"),   # low-rank accumulator: second chain launch with beta = 1
+    (8192, 320, 256, 50, False, 1.0, "lowrank64"), # ... a 64-wide one (both chains on two rank tiles, four k-steps)
     (8192, 768, 768, 8, True, 0.125, "dense"),     # config-4 style: fp32 dense accumulator + live rank 8
 ]
 
@@ -404,9 +405,10 @@ def test_chain3f_fp32_vs_oracle(case):
     B = torch.randn(r, d_out, generator=gen, device=DEV) * 0.05
     bias = torch.randn(d_out, generator=gen, device=DEV) * 0.1 if has_bias else None
     acc_down = acc_up = None
-    if acc == "lowrank":
-        acc_down = torch.randn(d_in, 24, generator=gen, device=DEV) * 0.05
-        acc_up = torch.randn(24, d_out, generator=gen, device=DEV) * 0.05
+    if acc in ("lowrank", "lowrank64"):
+        ra = 24 if acc == "lowrank" else 64
+        acc_down = torch.randn(d_in, ra, generator=gen, device=DEV) * 0.05
+        acc_up = torch.randn(ra, d_out, generator=gen, device=DEV) * 0.05
     elif acc == "dense":
         acc_down = torch.randn(d_in, d_out, generator=gen, device=DEV) * 0.02
     cpu = lambda t: None if t is None else t.cpu()
@@ -514,3 +516,26 @@ def test_chain3f_and_quad_kernel_random_shapes(seed):
     assert rel_err(dB.cpu(), dB_ref[0]) < 2e-5, what
     if has_bias:
         assert rel_err(db.cpu(), db_ref) < 2e-5, what
+
+
+def test_fp32_long_t_forward_without_workspace_falls_back():
+    """sow_forward_workspace_bytes is non-zero for fp32 inputs at T >= 8192 (factor planes of chain3f); a caller that passes
+    NULL / 0 anyway still gets the right answer (the launch takes the kernel that needs no scratch)."""
+    import ctypes
+    from sow_amd import _lib, ops
+    lib = _lib.load()
+    T, d_in, d_out, r = 8192, 256, 192, 50
+    assert lib.sow_forward_workspace_bytes(T, d_in, d_out, r, 0, _lib.ACC_NONE, _lib.F32) > 0
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(T, d_in, generator=gen, device=DEV)
+    A = torch.randn(d_in, r, generator=gen, device=DEV) * 0.05
+    B = torch.randn(r, d_out, generator=gen, device=DEV) * 0.05
+    y = torch.empty(T, d_out, device=DEV)
+    h = torch.empty(T * 64, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.sow_forward(x.data_ptr(), A.data_ptr(), B.data_ptr(), None, None, None, y.data_ptr(), h.data_ptr(), T, d_in, d_out, r, 0,
+                         _lib.ACC_NONE, ctypes.c_float(1.0), _lib.F32, None, 0, ctypes.c_void_p(stream))
+    assert rc == 0
+    y2, _ = ops.sow_forward(x, A, B, None, None, None, 1.0)
+    y_ref = O.sow_forward(x.cpu(), [A.cpu()], [B.cpu()], None, None, 1.0, None)
+    assert rel_err(y.cpu(), y_ref) < 1e-5 and rel_err(y2.cpu(), y_ref) < 1e-5
