@@ -342,7 +342,8 @@ template <int NT, int KS> __global__ __launch_bounds__(C4_THREADS, 2) void chain
       split3v(hacc[s4 >> 1][8 * (s4 & 1) + 2 * pr], hacc[s4 >> 1][8 * (s4 & 1) + 2 * pr + 1], hp[s4], pr);
   const uint32_t fo2 = (uint32_t)((32 * hh + li) * 128 + ((lh ^ ((li >> 1) & 7)) * 16));
   const bool rows_full = m0 + C4_BM <= p.M;
-  const bool plain = rows_full && p.beta == 0.f;           // unpredicated stores wherever the slice is full
+  const bool plain = rows_full;                            // unpredicated stores wherever the slice is full
+  const bool has_beta = p.beta != 0.f;                     // Y is accumulated onto (accumulator term written by an earlier launch)
   // per-lane byte offset of (token 4 lh, column 32 hh + li) from the wave's row base; register reg adds row (reg & 3) + 8 (reg >> 2)
   const float* ybase = p.Y + tok0 * p.ldy;                 // uniform per wave
   const uint32_t voff0 = (uint32_t)((4 * lh * p.ldy + 32 * hh + li) * 4);
@@ -354,6 +355,16 @@ template <int NT, int KS> __global__ __launch_bounds__(C4_THREADS, 2) void chain
     if (p.bias && col < D2) bv = p.bias[col];
     if (fast) {
       const float* sb = ybase + sl * 64;
+      if (has_beta) {   // the sixteen old values first (one 128-byte row segment per register, as the stores), then the stores
+        float old[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r = (reg & 3) + 8 * (reg >> 2);
+          old[reg] = *(const float*)((const char*)sb + voff0 + (uint32_t)(r * (int)p.ldy * 4));
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) yacc[reg] += p.beta * old[reg];
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int r = (reg & 3) + 8 * (reg >> 2);
@@ -395,7 +406,7 @@ template <int NT, int KS> __global__ __launch_bounds__(C4_THREADS, 2) void chain
     if (sl > 0) {
       const bool fast = plain && (sl * 64 <= D2);   // slice sl - 1 is full
       stores(sl - 1, fast);
-      prev_plain = fast && !p.bias;                 // (a bias load adds a compiler-counted operation: wait for everything)
+      prev_plain = fast && !p.bias && !has_beta;    // (bias / old-Y loads add compiler-counted operations: wait for everything)
     }
     LGKM_WAIT0();
 #pragma unroll
