@@ -389,6 +389,7 @@ C3F_CASES = [
     (8192, 256, 320, 16, True, 0.25, "lowrank"),   # low-rank accumulator: second chain launch with beta = 1
     (8192, 320, 256, 50, False, 1.0, "lowrank64"), # ... a 64-wide one (both chains on two rank tiles, four k-steps)
     (8192, 768, 768, 8, True, 0.125, "dense"),     # config-4 style: fp32 dense accumulator + live rank 8
+    (4100, 768, 320, 50, True, 1.0, None),         # below chain3f's threshold, above the quad kernel's: chain2f + quad, ragged T
 ]
 
 
