@@ -65,9 +65,12 @@ int sow_get_switch(const char* name);
 
 /* Bytes of workspace needed by sow_forward / sow_backward for this shape. */
 size_t sow_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);
-/* Bytes of workspace sow_forward itself touches: 0 for most shapes (the caller may then pass NULL / 0), else the
- * same figure as sow_workspace_bytes (a low-rank accumulator wider than 64; short bf16 inputs, whose chain is split
- * over K and over the output columns to fill the chip). */
+/* Bytes of workspace sow_forward itself touches: 0 for most bf16 shapes (the caller may then pass NULL / 0), else the
+ * same figure as sow_workspace_bytes (a low-rank accumulator wider than 64; short inputs, whose chain is split over K
+ * and over the output columns to fill the chip; fp32 inputs with T >= 8192, whose factors are pre-split into bf16 planes
+ * there; a bf16 dense accumulator at short T and long K, whose product is split over K).  A caller that passes NULL / 0
+ * where the query is non-zero still gets the right result from a slower kernel, except for the wide low-rank accumulator
+ * (SOW_ERR_WORKSPACE). */
 size_t sow_forward_workspace_bytes(int64_t T, int d_in, int d_out, int r_live, int r_acc, int acc_kind, int dtype);
 /* Elements (of dtype) the caller must allocate for h_save: T*64 when r_live <= 64, else T*r_live. */
 size_t sow_h_save_elems(int64_t T, int r_live);
